@@ -1,0 +1,310 @@
+// attention.hip -- small dense attention core (head dim 32, Lq/Lk <= 256) forward and backward.
+//
+// The CAPE decoder's sequences are tiny (L = 200 tokens, <= 68 support keypoints), so the whole K/V
+// (or Q/dO) panel of one (image, head) lives in LDS (<= 64 KB) and each query (key) row is owned by a
+// group of 4 lanes x 8 channels: dot products finish with two xor-shuffles, LDS reads of a key row
+// are wave-wide broadcasts (4 distinct addresses), no atomics anywhere:
+//   fwd      : thread group per query row, online softmax, saves LSE
+//   bwd dQ   : thread group per query row (recomputes P from LSE)
+//   bwd dK/dV: thread group per key row, loops over the queries
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 32;       // head dim
+constexpr int MAXL = 256;    // max staged rows
+constexpr int ROWS = 64;     // rows per block (x 4 lanes)
+
+struct AttnP {
+  long long ldq, ldk, ldv, ldo;
+  int N, H, Lq, Lk;
+  float scale;
+  int mask_mode, causal_offset;
+  const uint8_t* kpm;
+  uint32_t thresh; float inv_keep;
+  const uint64_t* rng_state; uint32_t rng_stream;
+};
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// cooperative load of `rows` x 32 floats (row stride ld) into LDS [rows][32]
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, long long ld, int rows) {
+  for (int idx = threadIdx.x; idx < rows * 8; idx += blockDim.x) {
+    const int r = idx >> 3, c = (idx & 7) * 4;
+    *reinterpret_cast<float4*>(dst + r * HD + c) = *reinterpret_cast<const float4*>(src + (long long)r * ld + c);
+  }
+}
+
+__device__ __forceinline__ float dot8(const float* a, const float4 b0, const float4 b1) {
+  return a[0] * b0.x + a[1] * b0.y + a[2] * b0.z + a[3] * b0.w + a[4] * b1.x + a[5] * b1.y + a[6] * b1.z + a[7] * b1.w;
+}
+
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                        const float* __restrict__ V, float* __restrict__ O,
+                                                        float* __restrict__ lse, const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + p.Lk * HD;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int sub = threadIdx.x & 3;
+  const int i = blockIdx.x * ROWS + (threadIdx.x >> 2);
+  stage_rows(Ks, K + (long long)n * p.Lk * p.ldk + h * HD, p.ldk, p.Lk);
+  stage_rows(Vs, V + (long long)n * p.Lk * p.ldv + h * HD, p.ldv, p.Lk);
+  __syncthreads();
+  const bool live = i < p.Lq;
+  float q[8], acc[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { q[d] = 0.f; acc[d] = 0.f; }
+  if (live) {
+    const float* qp = Q + ((long long)n * p.Lq + i) * p.ldq + h * HD + sub * 8;
+    const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+    q[0] = a.x * p.scale; q[1] = a.y * p.scale; q[2] = a.z * p.scale; q[3] = a.w * p.scale;
+    q[4] = b.x * p.scale; q[5] = b.y * p.scale; q[6] = b.z * p.scale; q[7] = b.w * p.scale;
+  }
+  uint64_t seed = 0, step = 0;
+  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  float m = -INFINITY, l = 0.f;
+  // wave-uniform loop bound (all lanes must take part in the shuffles)
+  int jend = p.Lk;
+  if (p.mask_mode == 1) {
+    const int last_row = min(p.Lq - 1, blockIdx.x * ROWS + ((threadIdx.x | 63) >> 2));
+    jend = min(p.Lk, last_row + p.causal_offset + 1);
+  }
+  const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
+  const uint64_t rbase = (((uint64_t)n * p.H + h) * p.Lq + (uint64_t)(live ? i : 0)) * p.Lk;
+  for (int j = 0; j < jend; ++j) {
+    const float4 k0 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8);
+    const float4 k1 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8 + 4);
+    float s = quad_sum(dot8(q, k0, k1));
+    bool masked = !live;
+    if (p.mask_mode == 1) masked = masked || (j > i + p.causal_offset);
+    if (kp) masked = masked || (kp[j] != 0);
+    if (masked) continue;                      // after the shuffle: safe
+    const float mn = fmaxf(m, s);
+    const float alpha = __expf(m - mn);        // m = -inf on the first unmasked key -> 0
+    const float pe = __expf(s - mn);
+    l = l * alpha + pe;
+    float pd = pe;
+    if (p.thresh) pd = cape_keep(seed, step, p.rng_stream, rbase + j, p.thresh) ? pe * p.inv_keep : 0.f;
+    const float4 v0 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8 + 4);
+    acc[0] = acc[0] * alpha + pd * v0.x; acc[1] = acc[1] * alpha + pd * v0.y;
+    acc[2] = acc[2] * alpha + pd * v0.z; acc[3] = acc[3] * alpha + pd * v0.w;
+    acc[4] = acc[4] * alpha + pd * v1.x; acc[5] = acc[5] * alpha + pd * v1.y;
+    acc[6] = acc[6] * alpha + pd * v1.z; acc[7] = acc[7] * alpha + pd * v1.w;
+    m = mn;
+  }
+  if (live) {
+    const float inv = 1.f / l;                 // l == 0 (fully masked row) -> NaN like torch
+    float* op = O + ((long long)n * p.Lq + i) * p.ldo + h * HD + sub * 8;
+    *reinterpret_cast<float4*>(op) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
+    if (sub == 0) lse[((long long)n * p.H + h) * p.Lq + i] = m + __logf(l);
+  }
+}
+
+// dQ: thread group per query row
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
+                                                           const float* __restrict__ K, const float* __restrict__ V,
+                                                           const float* __restrict__ O, const float* __restrict__ lse,
+                                                           float* __restrict__ dQ, const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + p.Lk * HD;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int sub = threadIdx.x & 3;
+  const int i = blockIdx.x * ROWS + (threadIdx.x >> 2);
+  stage_rows(Ks, K + (long long)n * p.Lk * p.ldk + h * HD, p.ldk, p.Lk);
+  stage_rows(Vs, V + (long long)n * p.Lk * p.ldv + h * HD, p.ldv, p.Lk);
+  __syncthreads();
+  const bool live = i < p.Lq;
+  float q[8], go[8], acc[8];
+  float D = 0.f, L = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { q[d] = 0.f; go[d] = 0.f; acc[d] = 0.f; }
+  if (live) {
+    const long long ro = (long long)n * p.Lq + i;
+    const float* qp = Q + ro * p.ldq + h * HD + sub * 8;
+    const float* gp = dO + ro * p.ldo + h * HD + sub * 8;
+    const float* op = O + ro * p.ldo + h * HD + sub * 8;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { q[d] = qp[d] * p.scale; go[d] = gp[d]; D += gp[d] * op[d]; }
+    L = lse[((long long)n * p.H + h) * p.Lq + i];
+  }
+  D = quad_sum(D);
+  uint64_t seed = 0, step = 0;
+  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  int jend = p.Lk;
+  if (p.mask_mode == 1) {
+    const int last_row = min(p.Lq - 1, blockIdx.x * ROWS + ((threadIdx.x | 63) >> 2));
+    jend = min(p.Lk, last_row + p.causal_offset + 1);
+  }
+  const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
+  const uint64_t rbase = (((uint64_t)n * p.H + h) * p.Lq + (uint64_t)(live ? i : 0)) * p.Lk;
+  for (int j = 0; j < jend; ++j) {
+    const float4 k0 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8);
+    const float4 k1 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8 + 4);
+    const float4 v0 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8 + 4);
+    const float s = quad_sum(dot8(q, k0, k1));
+    float dp = quad_sum(dot8(go, v0, v1));
+    bool masked = !live;
+    if (p.mask_mode == 1) masked = masked || (j > i + p.causal_offset);
+    if (kp) masked = masked || (kp[j] != 0);
+    if (masked) continue;
+    const float pe = __expf(s - L);
+    if (p.thresh) dp = cape_keep(seed, step, p.rng_stream, rbase + j, p.thresh) ? dp * p.inv_keep : 0.f;
+    const float ds = pe * (dp - D) * p.scale;
+    acc[0] += ds * k0.x; acc[1] += ds * k0.y; acc[2] += ds * k0.z; acc[3] += ds * k0.w;
+    acc[4] += ds * k1.x; acc[5] += ds * k1.y; acc[6] += ds * k1.z; acc[7] += ds * k1.w;
+  }
+  if (live) {
+    float* dp_ = dQ + ((long long)n * p.Lq + i) * p.ldq + h * HD + sub * 8;
+    *reinterpret_cast<float4*>(dp_) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(dp_ + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+// dK, dV: thread group per key row
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
+                                                            const float* __restrict__ K, const float* __restrict__ V,
+                                                            const float* __restrict__ O, const float* __restrict__ lse,
+                                                            float* __restrict__ dK, float* __restrict__ dV, const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;                       // [Lq][32]
+  float* Gs = smem + p.Lq * HD;           // dO [Lq][32]
+  float* Ds = smem + 2 * p.Lq * HD;       // D_i
+  float* Ls = Ds + p.Lq;                  // lse_i
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int sub = threadIdx.x & 3;
+  const int j = blockIdx.x * ROWS + (threadIdx.x >> 2);
+  stage_rows(Qs, Q + (long long)n * p.Lq * p.ldq + h * HD, p.ldq, p.Lq);
+  stage_rows(Gs, dO + (long long)n * p.Lq * p.ldo + h * HD, p.ldo, p.Lq);
+  for (int r = threadIdx.x; r < p.Lq; r += blockDim.x) {
+    const float* op = O + ((long long)n * p.Lq + r) * p.ldo + h * HD;
+    const float* gp = dO + ((long long)n * p.Lq + r) * p.ldo + h * HD;
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) d += op[c] * gp[c];
+    Ds[r] = d;
+    Ls[r] = lse[((long long)n * p.H + h) * p.Lq + r];
+  }
+  __syncthreads();
+  const bool live = j < p.Lk;
+  float k[8], v[8], ak[8], av[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { k[d] = 0.f; v[d] = 0.f; ak[d] = 0.f; av[d] = 0.f; }
+  bool keymasked = false;
+  if (live) {
+    const float* kp_ = K + ((long long)n * p.Lk + j) * p.ldk + h * HD + sub * 8;
+    const float* vp_ = V + ((long long)n * p.Lk + j) * p.ldv + h * HD + sub * 8;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { k[d] = kp_[d] * p.scale; v[d] = vp_[d]; }
+    if (p.mask_mode == 2) keymasked = p.kpm[(long long)n * p.Lk + j] != 0;
+  }
+  uint64_t seed = 0, step = 0;
+  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  // causal: key j is seen by queries i >= j - offset ; wave-uniform start = min over the wave's keys
+  int ibeg = 0;
+  if (p.mask_mode == 1) ibeg = max(0, blockIdx.x * ROWS + ((threadIdx.x & ~63) >> 2) - p.causal_offset);
+  for (int i = ibeg; i < p.Lq; ++i) {
+    const float4 q0 = *reinterpret_cast<const float4*>(Qs + i * HD + sub * 8);
+    const float4 q1 = *reinterpret_cast<const float4*>(Qs + i * HD + sub * 8 + 4);
+    const float4 g0 = *reinterpret_cast<const float4*>(Gs + i * HD + sub * 8);
+    const float4 g1 = *reinterpret_cast<const float4*>(Gs + i * HD + sub * 8 + 4);
+    const float s = quad_sum(dot8(k, q0, q1));
+    float dp = quad_sum(dot8(v, g0, g1));
+    bool masked = !live || keymasked;
+    if (p.mask_mode == 1) masked = masked || (j > i + p.causal_offset);
+    if (masked) continue;
+    const float pe = __expf(s - Ls[i]);
+    float pd = pe;
+    if (p.thresh) {
+      const bool keep = cape_keep(seed, step, p.rng_stream, (((uint64_t)n * p.H + h) * p.Lq + i) * p.Lk + j, p.thresh);
+      pd = keep ? pe * p.inv_keep : 0.f;
+      dp = keep ? dp * p.inv_keep : 0.f;
+    }
+    av[0] += pd * g0.x; av[1] += pd * g0.y; av[2] += pd * g0.z; av[3] += pd * g0.w;
+    av[4] += pd * g1.x; av[5] += pd * g1.y; av[6] += pd * g1.z; av[7] += pd * g1.w;
+    const float ds = pe * (dp - Ds[i]) * p.scale;
+    ak[0] += ds * q0.x; ak[1] += ds * q0.y; ak[2] += ds * q0.z; ak[3] += ds * q0.w;
+    ak[4] += ds * q1.x; ak[5] += ds * q1.y; ak[6] += ds * q1.z; ak[7] += ds * q1.w;
+  }
+  if (live) {
+    float* dk = dK + ((long long)n * p.Lk + j) * p.ldk + h * HD + sub * 8;
+    float* dv = dV + ((long long)n * p.Lk + j) * p.ldv + h * HD + sub * 8;
+    *reinterpret_cast<float4*>(dk) = make_float4(ak[0], ak[1], ak[2], ak[3]);
+    *reinterpret_cast<float4*>(dk + 4) = make_float4(ak[4], ak[5], ak[6], ak[7]);
+    *reinterpret_cast<float4*>(dv) = make_float4(av[0], av[1], av[2], av[3]);
+    *reinterpret_cast<float4*>(dv + 4) = make_float4(av[4], av[5], av[6], av[7]);
+  }
+}
+
+int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, int N, int H, int Lq, int Lk, float scale,
+         int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
+         uint32_t rng_stream) {
+  CAPE_REQUIRE(Lq >= 1 && Lk >= 1 && Lq <= MAXL && Lk <= MAXL, "cape_attn: Lq=%d Lk=%d must be in 1..%d", Lq, Lk, MAXL);
+  CAPE_REQUIRE((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0, "cape_attn: row strides must be multiples of 4");
+  CAPE_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "cape_attn: bad mask_mode %d", mask_mode);
+  CAPE_REQUIRE(mask_mode != 2 || kpm, "cape_attn: key padding mask missing");
+  CAPE_REQUIRE(dropout_p == 0.f || (rng_state && dropout_p < 1.f), "cape_attn: dropout needs rng_state");
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.N = N; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+  p.mask_mode = mask_mode; p.causal_offset = causal_offset; p.kpm = kpm;
+  p.thresh = dropout_p > 0.f ? cape_drop_threshold(dropout_p) : 0u;
+  p.inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  p.rng_state = rng_state; p.rng_stream = rng_stream;
+  return 0;
+}
+
+int raise_lds_limit() {
+  static bool done = false;
+  if (done) return 0;
+  const int lim = 96 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  if (e != hipSuccess) return cape_set_error("cape_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  done = true;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cape_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, long long ldq,
+                             long long ldk, long long ldv, long long ldo, int N, int H, int Lq, int Lk, float scale,
+                             int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p,
+                             const uint64_t* rng_state, uint32_t rng_stream, cape_stream_t stream) {
+  CAPE_REQUIRE(Q && K && V && O && lse, "cape_attn_fwd: null pointer");
+  if (N <= 0 || H <= 0) return 0;
+  AttnP p;
+  if (fill(p, ldq, ldk, ldv, ldo, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
+  if (raise_lds_limit()) return 1;
+  const size_t sh = (size_t)2 * Lk * HD * sizeof(float);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh, as_stream(stream), Q, K, V, O, lse, p);
+  CAPE_LAUNCH_CHECK("cape_attn_fwd");
+  return 0;
+}
+
+extern "C" int cape_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* O,
+                             const float* lse, float* dQ, float* dK, float* dV, long long ldq, long long ldk,
+                             long long ldv, long long ldo, int N, int H, int Lq, int Lk, float scale, int mask_mode,
+                             int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
+                             uint32_t rng_stream, cape_stream_t stream) {
+  CAPE_REQUIRE(dO && Q && K && V && O && lse && dQ && dK && dV, "cape_attn_bwd: null pointer");
+  if (N <= 0 || H <= 0) return 0;
+  AttnP p;
+  if (fill(p, ldq, ldk, ldv, ldo, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
+  if (raise_lds_limit()) return 1;
+  const size_t sh1 = (size_t)2 * Lk * HD * sizeof(float);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh1, as_stream(stream), dO, Q, K, V,
+                     O, lse, dQ, p);
+  const size_t sh2 = ((size_t)2 * Lq * HD + 2 * Lq) * sizeof(float);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + ROWS - 1) / ROWS, H, N), dim3(256), sh2, as_stream(stream), dO, Q, K, V,
+                     O, lse, dK, dV, p);
+  CAPE_LAUNCH_CHECK("cape_attn_bwd");
+  return 0;
+}

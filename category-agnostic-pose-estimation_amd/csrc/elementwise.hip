@@ -1,0 +1,435 @@
+// elementwise.hip -- HBM-bound pointwise / small-row kernels of the CAPE path (gfx950).
+// Grid-stride loops, 16-byte accesses where the layout allows; transcendental tables
+// (the 128-entry `dim_t` temperature table) come from the host so the values match torch bit for bit.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned grid_for(long long n, int per = 1) {
+  long long b = (n + (long long)TPB * per - 1) / ((long long)TPB * per);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+#define GSTRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__global__ void add_kernel(const float* a, const float* b, float* o, long long n) {
+  const long long n4 = n >> 2;
+  GSTRIDE(i, n4) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(o)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  GSTRIDE(i, n & 3) o[(n4 << 2) + i] = a[(n4 << 2) + i] + b[(n4 << 2) + i];
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* x, float* o, int N, int C, int H, int W, int Cp) {
+  const long long tot = (long long)N * H * W * Cp;
+  GSTRIDE(i, tot) {
+    const int c = (int)(i % Cp);
+    const long long pix = i / Cp;
+    const int w = (int)(pix % W);
+    const long long t = pix / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    o[i] = c < C ? x[(((long long)n * C + c) * H + h) * W + w] : 0.f;
+  }
+}
+
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float eps, float* sc,
+                               float* sh, int C) {
+  GSTRIDE(i, C) {
+    const float s = w[i] * rsqrtf(rv[i] + eps);
+    sc[i] = s;
+    sh[i] = b[i] - rm[i] * s;
+  }
+}
+
+__global__ void maxpool_kernel(const float* x, float* o, int N, int H, int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long long tot = (long long)N * OH * OW * C4;
+  GSTRIDE(i, tot) {
+    const int c = (int)(i % C4) * 4;
+    const long long pix = i / C4;
+    const int ox = (int)(pix % OW);
+    const long long t = pix / OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if (iy < 0 || iy >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long long)n * H + iy) * W + ix) * C + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(o + pix * C + c) = m;
+  }
+}
+
+__global__ void bn_relu_bwd_kernel(const float* dy, const float* y, const float* scale, float* d_pre, float* d_res,
+                                   long long rows, int C, int relu) {
+  const int C4 = C >> 2;
+  const long long tot = rows * C4;
+  GSTRIDE(i, tot) {
+    const int c = (int)(i % C4) * 4;
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    if (relu) {
+      const float4 v = reinterpret_cast<const float4*>(y)[i];
+      g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f;
+      g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
+    }
+    if (d_res) reinterpret_cast<float4*>(d_res)[i] = g;
+    if (scale) {
+      const float4 s = *reinterpret_cast<const float4*>(scale + c);
+      g.x *= s.x; g.y *= s.y; g.z *= s.z; g.w *= s.w;
+    }
+    reinterpret_cast<float4*>(d_pre)[i] = g;
+  }
+}
+
+__global__ void relu_drop_bwd_kernel(const float* dh, const float* h, float* d_pre, long long n, float inv_keep) {
+  GSTRIDE(i, n) d_pre[i] = h[i] > 0.f ? dh[i] * inv_keep : 0.f;
+}
+
+// image sine position embedding (+ level embedding); thread = (n, pixel, channel)
+__global__ void pos_sine_level_kernel(const uint8_t* mask, const float* lvl, const float* dim_t, float* out,
+                                      long long image_stride, int N, int h, int w, int C) {
+  const int half = C >> 1;
+  const long long tot = (long long)N * h * w * C;
+  GSTRIDE(i, tot) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    const int x = (int)(pix % w);
+    const long long t = pix / w;
+    const int y = (int)(t % h);
+    const int n = (int)(t / h);
+    const uint8_t* m = mask + (long long)n * h * w;
+    float e, tot_e;
+    if (c < half) {   // pos_y block: cumsum over rows of this column
+      int cs = 0, all = 0;
+      for (int r = 0; r < h; ++r) { const int v = m[r * w + x] == 0; all += v; if (r <= y) cs += v; }
+      e = (float)cs; tot_e = (float)all;
+    } else {
+      int cs = 0, all = 0;
+      for (int q = 0; q < w; ++q) { const int v = m[y * w + q] == 0; all += v; if (q <= x) cs += v; }
+      e = (float)cs; tot_e = (float)all;
+    }
+    const int k = c < half ? c : c - half;
+    const float v = (e - 0.5f) / (tot_e + 1e-6f) * 6.283185307179586f / dim_t[k];
+    const float r = (k & 1) ? cosf(v) : sinf(v);
+    out[(long long)n * image_stride + ((long long)y * w + x) * C + c] = r + lvl[c];
+  }
+}
+
+// ---- token embedding -------------------------------------------------------------------------
+__global__ void token_embed_fwd_kernel(const float* table, const int64_t* s11, const int64_t* s21, const int64_t* s12,
+                                       const int64_t* s22, const float* dx1, const float* dx2, const float* dy1,
+                                       const float* dy2, float* out, long long R, int C) {
+  const int C4 = C >> 2;
+  const long long tot = R * C4;
+  GSTRIDE(i, tot) {
+    const long long r = i / C4;
+    const int c = (int)(i % C4) * 4;
+    const float w11 = dx2[r] * dy2[r], w21 = dx1[r] * dy2[r], w12 = dx2[r] * dy1[r], w22 = dx1[r] * dy1[r];
+    const float4 a = *reinterpret_cast<const float4*>(table + s11[r] * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(table + s21[r] * C + c);
+    const float4 d = *reinterpret_cast<const float4*>(table + s12[r] * C + c);
+    const float4 e = *reinterpret_cast<const float4*>(table + s22[r] * C + c);
+    // same association order as the reference expression (e11*dx2*dy2 + e21*dx1*dy2 + e12*dx2*dy1 + e22*dx1*dy1)
+    float4 o;
+    o.x = a.x * dx2[r] * dy2[r] + b.x * dx1[r] * dy2[r] + d.x * dx2[r] * dy1[r] + e.x * dx1[r] * dy1[r];
+    o.y = a.y * dx2[r] * dy2[r] + b.y * dx1[r] * dy2[r] + d.y * dx2[r] * dy1[r] + e.y * dx1[r] * dy1[r];
+    o.z = a.z * dx2[r] * dy2[r] + b.z * dx1[r] * dy2[r] + d.z * dx2[r] * dy1[r] + e.z * dx1[r] * dy1[r];
+    o.w = a.w * dx2[r] * dy2[r] + b.w * dx1[r] * dy2[r] + d.w * dx2[r] * dy1[r] + e.w * dx1[r] * dy1[r];
+    (void)w11; (void)w21; (void)w12; (void)w22;
+    *reinterpret_cast<float4*>(out + r * C + c) = o;
+  }
+}
+
+__global__ void token_embed_bwd_kernel(const float* d_out, const int64_t* s11, const int64_t* s21, const int64_t* s12,
+                                       const int64_t* s22, const float* dx1, const float* dx2, const float* dy1,
+                                       const float* dy2, float* d_table, long long R, int C, int pad_idx) {
+  const long long tot = R * C;
+  GSTRIDE(i, tot) {
+    const long long r = i / C;
+    const int c = (int)(i % C);
+    const float g = d_out[i];
+    const int64_t i11 = s11[r], i21 = s21[r], i12 = s12[r], i22 = s22[r];
+    if (i11 != pad_idx) atomicAdd(d_table + i11 * C + c, g * dx2[r] * dy2[r]);
+    if (i21 != pad_idx) atomicAdd(d_table + i21 * C + c, g * dx1[r] * dy2[r]);
+    if (i12 != pad_idx) atomicAdd(d_table + i12 * C + c, g * dx2[r] * dy1[r]);
+    if (i22 != pad_idx) atomicAdd(d_table + i22 * C + c, g * dx1[r] * dy1[r]);
+  }
+}
+
+// ---- decoder query sine embedding ---------------------------------------------------------------
+__global__ void query_sine_fwd_kernel(const float* ref, const float* dim_t, float* out, long long R) {
+  const long long tot = R * 256;
+  GSTRIDE(i, tot) {
+    const long long r = i >> 8;
+    const int c = (int)(i & 255);
+    const int a = c >> 7, k = c & 127;
+    const float v = ref[r * 2 + a] * 6.283185307179586f / dim_t[k];
+    out[i] = (k & 1) ? cosf(v) : sinf(v);
+  }
+}
+
+__global__ void __launch_bounds__(256) query_sine_bwd_kernel(const float* d_out, const float* ref, const float* dim_t,
+                                                              float* d_ref, int accumulate, long long R) {
+  __shared__ float part[4];
+  const long long r = blockIdx.x;
+  const int c = threadIdx.x;
+  const int a = c >> 7, k = c & 127;
+  const float sc = 6.283185307179586f / dim_t[k];
+  const float v = ref[r * 2 + a] * 6.283185307179586f / dim_t[k];
+  const float g = d_out[r * 256 + c] * ((k & 1) ? -sinf(v) : cosf(v)) * sc;
+  const float s = wave_sum(g);
+  if ((c & 63) == 0) part[c >> 6] = s;
+  __syncthreads();
+  if (c < 2) {
+    const float t = part[2 * c] + part[2 * c + 1];
+    if (accumulate) d_ref[r * 2 + c] += t; else d_ref[r * 2 + c] = t;
+  }
+}
+
+// ---- refinement / sigmoid -----------------------------------------------------------------------
+__device__ __forceinline__ float inv_sigmoid(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float x1 = fmaxf(x, 1e-5f), x2 = fmaxf(1.f - x, 1e-5f);
+  return logf(x1 / x2);
+}
+__global__ void refine_fwd_kernel(const float* delta, const float* ref, float* out, long long n) {
+  GSTRIDE(i, n) {
+    const float z = delta[i] + inv_sigmoid(ref[i]);
+    out[i] = 1.f / (1.f + expf(-z));
+  }
+}
+__global__ void refine_bwd_kernel(const float* d_new, const float* new_ref, const float* ref, float* d_delta, float* d_ref,
+                                  int acc, long long n) {
+  GSTRIDE(i, n) {
+    const float s = new_ref[i];
+    const float dz = d_new[i] * s * (1.f - s);
+    d_delta[i] = dz;
+    if (d_ref) {
+      const float x = ref[i];
+      float dx = 0.f;
+      if (x >= 0.f && x <= 1.f) {
+        if (x >= 1e-5f) dx += 1.f / x;                 // d log(max(x, eps))
+        if (1.f - x >= 1e-5f) dx += 1.f / (1.f - x);   // d -log(max(1-x, eps))
+      }
+      const float g = dz * dx;
+      if (acc) d_ref[i] += g; else d_ref[i] = g;
+    }
+  }
+}
+__global__ void sigmoid_fwd_kernel(const float* x, float* y, long long n) {
+  GSTRIDE(i, n) y[i] = 1.f / (1.f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* dy, const float* y, float* dx, int acc, long long n) {
+  GSTRIDE(i, n) {
+    const float g = dy[i] * y[i] * (1.f - y[i]);
+    if (acc) dx[i] += g; else dx[i] = g;
+  }
+}
+__global__ void ref_scale_fwd_kernel(const float* ref, const float* vr, float* out, long long R, int rpi, int L) {
+  const long long tot = R * L * 2;
+  GSTRIDE(i, tot) {
+    const int a = (int)(i & 1);
+    const long long t = i >> 1;
+    const int l = (int)(t % L);
+    const long long r = t / L;
+    const long long n = r / rpi;
+    out[i] = ref[r * 2 + a] * vr[(n * L + l) * 2 + a];
+  }
+}
+__global__ void ref_scale_bwd_kernel(const float* d_in, const float* vr, float* d_ref, int acc, long long R, int rpi, int L) {
+  const long long tot = R * 2;
+  GSTRIDE(i, tot) {
+    const int a = (int)(i & 1);
+    const long long r = i >> 1;
+    const long long n = r / rpi;
+    float g = 0.f;
+    for (int l = 0; l < L; ++l) g += d_in[(r * L + l) * 2 + a] * vr[(n * L + l) * 2 + a];
+    if (acc) d_ref[i] += g; else d_ref[i] = g;
+  }
+}
+__global__ void zero_rows_kernel(float* x, const uint8_t* rowmask, long long rows, int C) {
+  const long long tot = rows * C;
+  GSTRIDE(i, tot) if (rowmask[i / C]) x[i] = 0.f;
+}
+
+}  // namespace
+
+#define LAUNCH1(kern, n, per, ...)                                                               \
+  hipLaunchKernelGGL(kern, dim3(grid_for((n), (per))), dim3(TPB), 0, as_stream(stream), __VA_ARGS__)
+
+extern "C" int cape_add_f32(const float* a, const float* b, float* out, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(a && b && out && n >= 0, "cape_add_f32: bad arguments");
+  if (n == 0) return 0;
+  CAPE_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+               "cape_add_f32: pointers must be 16-byte aligned");
+  LAUNCH1(add_kernel, n / 4 + 1, 1, a, b, out, n);
+  CAPE_LAUNCH_CHECK("cape_add_f32");
+  return 0;
+}
+
+extern "C" int cape_nchw_to_nhwc(const float* x, float* out, int N, int C, int H, int W, int Cp, cape_stream_t stream) {
+  CAPE_REQUIRE(x && out && Cp >= C && C > 0, "cape_nchw_to_nhwc: bad arguments");
+  const long long n = (long long)N * H * W * Cp;
+  if (n == 0) return 0;
+  LAUNCH1(nchw_to_nhwc_kernel, n, 1, x, out, N, C, H, W, Cp);
+  CAPE_LAUNCH_CHECK("cape_nchw_to_nhwc");
+  return 0;
+}
+
+extern "C" int cape_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, float* scale,
+                            float* shift, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(w && b && rm && rv && scale && shift && C > 0, "cape_bn_fold: bad arguments");
+  LAUNCH1(bn_fold_kernel, C, 1, w, b, rm, rv, eps, scale, shift, C);
+  CAPE_LAUNCH_CHECK("cape_bn_fold");
+  return 0;
+}
+
+extern "C" int cape_maxpool3x3s2_nhwc(const float* x, float* out, int N, int H, int W, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(x && out && (C % 4) == 0, "cape_maxpool3x3s2_nhwc: bad arguments (C %% 4 != 0?)");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long long n = (long long)N * OH * OW * (C / 4);
+  if (n == 0) return 0;
+  LAUNCH1(maxpool_kernel, n, 1, x, out, N, H, W, C, OH, OW);
+  CAPE_LAUNCH_CHECK("cape_maxpool3x3s2_nhwc");
+  return 0;
+}
+
+extern "C" int cape_bn_relu_bwd(const float* dy, const float* y, const float* scale, float* d_pre, float* d_res,
+                                long long rows, int C, int relu, cape_stream_t stream) {
+  CAPE_REQUIRE(dy && d_pre && (C % 4) == 0 && (!relu || y), "cape_bn_relu_bwd: bad arguments");
+  const long long n = rows * (C / 4);
+  if (n == 0) return 0;
+  LAUNCH1(bn_relu_bwd_kernel, n, 1, dy, y, scale, d_pre, d_res, rows, C, relu);
+  CAPE_LAUNCH_CHECK("cape_bn_relu_bwd");
+  return 0;
+}
+
+extern "C" int cape_relu_drop_bwd(const float* dh, const float* h, float* d_pre, long long n, float inv_keep,
+                                  cape_stream_t stream) {
+  CAPE_REQUIRE(dh && h && d_pre, "cape_relu_drop_bwd: null pointer");
+  if (n == 0) return 0;
+  LAUNCH1(relu_drop_bwd_kernel, n, 4, dh, h, d_pre, n, inv_keep);
+  CAPE_LAUNCH_CHECK("cape_relu_drop_bwd");
+  return 0;
+}
+
+extern "C" int cape_pos_sine_level(const uint8_t* mask, const float* level_embed_l, const float* dim_t, float* out,
+                                   long long out_image_stride, int N, int h, int w, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(mask && level_embed_l && dim_t && out && C == 256, "cape_pos_sine_level: bad arguments (C must be 256)");
+  const long long n = (long long)N * h * w * C;
+  if (n == 0) return 0;
+  LAUNCH1(pos_sine_level_kernel, n, 1, mask, level_embed_l, dim_t, out, out_image_stride, N, h, w, C);
+  CAPE_LAUNCH_CHECK("cape_pos_sine_level");
+  return 0;
+}
+
+extern "C" int cape_token_embed_fwd(const float* table, const int64_t* s11, const int64_t* s21, const int64_t* s12,
+                                    const int64_t* s22, const float* dx1, const float* dx2, const float* dy1,
+                                    const float* dy2, float* out, long long R, int C, int vocab, cape_stream_t stream) {
+  CAPE_REQUIRE(table && s11 && s21 && s12 && s22 && dx1 && dx2 && dy1 && dy2 && out && (C % 4) == 0 && vocab > 0,
+               "cape_token_embed_fwd: bad arguments");
+  if (R == 0) return 0;
+  LAUNCH1(token_embed_fwd_kernel, R * (C / 4), 1, table, s11, s21, s12, s22, dx1, dx2, dy1, dy2, out, R, C);
+  CAPE_LAUNCH_CHECK("cape_token_embed_fwd");
+  return 0;
+}
+
+extern "C" int cape_token_embed_bwd(const float* d_out, const int64_t* s11, const int64_t* s21, const int64_t* s12,
+                                    const int64_t* s22, const float* dx1, const float* dx2, const float* dy1,
+                                    const float* dy2, float* d_table, long long R, int C, int vocab, int pad_idx,
+                                    cape_stream_t stream) {
+  CAPE_REQUIRE(d_out && s11 && s21 && s12 && s22 && dx1 && dx2 && dy1 && dy2 && d_table && vocab > 0,
+               "cape_token_embed_bwd: bad arguments");
+  if (R == 0) return 0;
+  LAUNCH1(token_embed_bwd_kernel, R * C, 1, d_out, s11, s21, s12, s22, dx1, dx2, dy1, dy2, d_table, R, C, pad_idx);
+  CAPE_LAUNCH_CHECK("cape_token_embed_bwd");
+  return 0;
+}
+
+extern "C" int cape_query_sine_fwd(const float* ref, const float* dim_t, float* out, long long R, cape_stream_t stream) {
+  CAPE_REQUIRE(ref && dim_t && out, "cape_query_sine_fwd: null pointer");
+  if (R == 0) return 0;
+  LAUNCH1(query_sine_fwd_kernel, R * 256, 1, ref, dim_t, out, R);
+  CAPE_LAUNCH_CHECK("cape_query_sine_fwd");
+  return 0;
+}
+
+extern "C" int cape_query_sine_bwd(const float* d_out, const float* ref, const float* dim_t, float* d_ref, int accumulate,
+                                   long long R, cape_stream_t stream) {
+  CAPE_REQUIRE(d_out && ref && dim_t && d_ref && R < (1ll << 31), "cape_query_sine_bwd: bad arguments");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(query_sine_bwd_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), d_out, ref, dim_t, d_ref,
+                     accumulate, R);
+  CAPE_LAUNCH_CHECK("cape_query_sine_bwd");
+  return 0;
+}
+
+extern "C" int cape_refine_fwd(const float* delta, const float* ref, float* new_ref, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(delta && ref && new_ref, "cape_refine_fwd: null pointer");
+  if (n == 0) return 0;
+  LAUNCH1(refine_fwd_kernel, n, 1, delta, ref, new_ref, n);
+  CAPE_LAUNCH_CHECK("cape_refine_fwd");
+  return 0;
+}
+
+extern "C" int cape_refine_bwd(const float* d_new, const float* new_ref, const float* ref, float* d_delta, float* d_ref,
+                               int accumulate_ref, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(d_new && new_ref && ref && d_delta, "cape_refine_bwd: null pointer");
+  if (n == 0) return 0;
+  LAUNCH1(refine_bwd_kernel, n, 1, d_new, new_ref, ref, d_delta, d_ref, accumulate_ref, n);
+  CAPE_LAUNCH_CHECK("cape_refine_bwd");
+  return 0;
+}
+
+extern "C" int cape_sigmoid_fwd(const float* x, float* y, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(x && y, "cape_sigmoid_fwd: null pointer");
+  if (n == 0) return 0;
+  LAUNCH1(sigmoid_fwd_kernel, n, 1, x, y, n);
+  CAPE_LAUNCH_CHECK("cape_sigmoid_fwd");
+  return 0;
+}
+
+extern "C" int cape_sigmoid_bwd(const float* dy, const float* y, float* dx, int accumulate, long long n,
+                                cape_stream_t stream) {
+  CAPE_REQUIRE(dy && y && dx, "cape_sigmoid_bwd: null pointer");
+  if (n == 0) return 0;
+  LAUNCH1(sigmoid_bwd_kernel, n, 1, dy, y, dx, accumulate, n);
+  CAPE_LAUNCH_CHECK("cape_sigmoid_bwd");
+  return 0;
+}
+
+extern "C" int cape_ref_scale_fwd(const float* ref, const float* valid_ratios, float* ref_in, long long R,
+                                  int rows_per_image, int L, cape_stream_t stream) {
+  CAPE_REQUIRE(ref && valid_ratios && ref_in && rows_per_image > 0 && L > 0, "cape_ref_scale_fwd: bad arguments");
+  if (R == 0) return 0;
+  LAUNCH1(ref_scale_fwd_kernel, R * L * 2, 1, ref, valid_ratios, ref_in, R, rows_per_image, L);
+  CAPE_LAUNCH_CHECK("cape_ref_scale_fwd");
+  return 0;
+}
+
+extern "C" int cape_ref_scale_bwd(const float* d_ref_in, const float* valid_ratios, float* d_ref, int accumulate,
+                                  long long R, int rows_per_image, int L, cape_stream_t stream) {
+  CAPE_REQUIRE(d_ref_in && valid_ratios && d_ref && rows_per_image > 0 && L > 0, "cape_ref_scale_bwd: bad arguments");
+  if (R == 0) return 0;
+  LAUNCH1(ref_scale_bwd_kernel, R * 2, 1, d_ref_in, valid_ratios, d_ref, accumulate, R, rows_per_image, L);
+  CAPE_LAUNCH_CHECK("cape_ref_scale_bwd");
+  return 0;
+}
+
+extern "C" int cape_zero_rows(float* x, const uint8_t* rowmask, long long rows, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(x && rowmask && C > 0, "cape_zero_rows: bad arguments");
+  if (rows == 0) return 0;
+  LAUNCH1(zero_rows_kernel, rows * C, 1, x, rowmask, rows, C);
+  CAPE_LAUNCH_CHECK("cape_zero_rows");
+  return 0;
+}

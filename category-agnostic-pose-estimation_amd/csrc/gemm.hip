@@ -1,0 +1,430 @@
+// gemm.hip -- implicit-GEMM family on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// One kernel template covers nn.Linear fwd/dgrad/wgrad and NHWC convolution fwd/dgrad/wgrad
+// (the A/B operand "modes" of cape_hip.h).  Design (MI355X):
+//   * 256 threads = 4 wave64 in a 2x2 arrangement; block tile BMxBN (128x128 or 64x64), BK = 32;
+//   * operands are staged global -> registers -> LDS (one tile of prefetch in registers, so the
+//     HBM/L2 latency of tile t+1 hides under the MFMAs of tile t);
+//   * K-contiguous sources are kept row-major in LDS with a 36-float row stride (conflict-free
+//     ds_read_b128: every lane fetches 4 consecutive k of its row); the physical k order inside a
+//     group of 8 is permuted identically for A and B so one b128 read feeds 4 MFMAs
+//     (MFMA step s of group g multiplies k = 8g + 4*(lane>>5) + s);
+//   * M/N-contiguous sources (transposed operands, gathers along channels) are kept [k][mn] and
+//     read with ds_read_b32 (32 consecutive floats per half wave: conflict-free);
+//   * fp32 MFMA is 64 cycles per 32x32x2 step, so LDS and issue bandwidth are far from binding;
+//     what matters is grid fill (>= 2 tiles per CU or split-K) and L2 locality (XCD-aware tile order).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct GemmP {
+  int M, N, K;
+  const float* A; long long lda;
+  const float* B; long long ldb;
+  float* C; long long ldc;
+  int cN, cH, cW, cC, cKH, cKW, cStride, cPad, cOH, cOW, cO;
+  const float* scale; const float* bias; const float* residual; long long ldr;
+  int relu, accumulate, split_k;
+  uint32_t drop_thresh; float inv_keep;
+  const uint64_t* rng_state; uint32_t rng_stream;
+  int tilesM, tilesN;
+};
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// guarded 4-float load: `valid` leading elements exist (0..4); vector path needs 16-B alignment
+__device__ __forceinline__ float4 ldg4(const float* p, int valid) {
+  if (valid >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) return *reinterpret_cast<const float4*>(p);
+  float4 r = zero4();
+  if (valid > 0) r.x = p[0];
+  if (valid > 1) r.y = p[1];
+  if (valid > 2) r.z = p[2];
+  if (valid > 3) r.w = p[3];
+  return r;
+}
+
+constexpr int BK = 32;
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
+  constexpr bool A_KC = (AMODE == 0 || AMODE == 2 || AMODE == 3);
+  constexpr bool B_KC = (BMODE == 0);
+  constexpr int A_LD = A_KC ? 36 : (BM + 4);
+  constexpr int B_LD = B_KC ? 36 : (BN + 4);
+  constexpr int A_SZ = A_KC ? BM * 36 : BK * (BM + 4);
+  constexpr int B_SZ = B_KC ? BN * 36 : BK * (BN + 4);
+  constexpr int NA = BM / 32;   // 16-byte chunks per thread per k-tile
+  constexpr int NB = BN / 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TI = WTM / 32, TJ = WTN / 32;
+
+  __shared__ __attribute__((aligned(16))) float As[A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[B_SZ];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+  //      run of tile ids so neighbouring tiles (same A rows / same B columns) hit the same L2.
+  const int ntiles = p.tilesM * p.tilesN;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- split-K range
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int per = (ktiles + p.split_k - 1) / p.split_k;
+  const int kt_begin = blockIdx.y * per;
+  const int kt_end = min(ktiles, kt_begin + per);
+  if (kt_begin >= kt_end) return;
+
+  // ---- per-thread load coordinates
+  // K-contig: chunk column kc = t&7 (k offset 4kc), rows (t>>3) + 32j
+  // MN-contig: chunks per k-row CH = B?/4; column mc = t % CH, k-row (t / CH) + (256/CH) j
+  const int a_kc = t & 7, a_r0 = t >> 3;
+  constexpr int A_CH = BM / 4;
+  const int a_mc = t % A_CH, a_k0 = t / A_CH;
+  constexpr int A_KSTEP = 256 / A_CH;
+  const int b_kc = t & 7, b_r0 = t >> 3;
+  constexpr int B_CH = BN / 4;
+  const int b_mc = t % B_CH, b_k0 = t / B_CH;
+  constexpr int B_KSTEP = 256 / B_CH;
+
+  // conv gather row decode (AMODE 2: rows are output positions; AMODE 3: rows are input positions)
+  int a_n[NA], a_y[NA], a_x[NA];
+  if constexpr (AMODE == 2 || AMODE == 3) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int row = m0 + a_r0 + 32 * j;
+      if (row < p.M) {
+        const int RW = (AMODE == 2) ? p.cOW : p.cW;
+        const int RH = (AMODE == 2) ? p.cOH : p.cH;
+        const int x = row % RW;
+        const int tq = row / RW;
+        const int y = tq % RH;
+        a_n[j] = tq / RH;
+        if (AMODE == 2) { a_y[j] = y * p.cStride - p.cPad; a_x[j] = x * p.cStride - p.cPad; }
+        else { a_y[j] = y + p.cPad; a_x[j] = x + p.cPad; }
+      } else {
+        a_n[j] = -1; a_y[j] = 0; a_x[j] = 0;
+      }
+    }
+  }
+
+  float4 ra[NA], rb[NB];
+
+  auto load_tiles = [&](int kt) {
+    const int kbase = kt * BK;
+    // ---------------- A ----------------
+    if constexpr (AMODE == 0) {
+      const int k = kbase + 4 * a_kc;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int row = m0 + a_r0 + 32 * j;
+        const int valid = (row < p.M) ? min(4, max(0, p.K - k)) : 0;
+        ra[j] = valid ? ldg4(p.A + (long long)row * p.lda + k, valid) : zero4();
+      }
+    } else if constexpr (AMODE == 1) {
+      const int mcol = m0 + 4 * a_mc;
+      const int vm = min(4, max(0, p.M - mcol));
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int k = kbase + a_k0 + A_KSTEP * j;
+        ra[j] = (k < p.K && vm) ? ldg4(p.A + (long long)k * p.lda + mcol, vm) : zero4();
+      }
+    } else if constexpr (AMODE == 2) {
+      const int k = kbase + 4 * a_kc;
+      const int tap = k / p.cC, c = k - tap * p.cC;
+      const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int iy = a_y[j] + kh, ix = a_x[j] + kw;
+        const bool ok = (a_n[j] >= 0) && (k < p.K) && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        ra[j] = ok ? *reinterpret_cast<const float4*>(p.A + (((long long)a_n[j] * p.cH + iy) * p.cW + ix) * p.cC + c)
+                   : zero4();
+      }
+    } else {  // AMODE == 3: dgrad gather of dY (N, OH, OW, O); k = tap*O + o
+      const int k = kbase + 4 * a_kc;
+      const int tap = k / p.cO, o = k - tap * p.cO;
+      const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int ty = a_y[j] - kh, tx = a_x[j] - kw;
+        bool ok = (a_n[j] >= 0) && (k < p.K) && ty >= 0 && tx >= 0;
+        int oy = ty, ox = tx;
+        if (p.cStride != 1) {
+          oy = ty / p.cStride; ox = tx / p.cStride;
+          ok = ok && (oy * p.cStride == ty) && (ox * p.cStride == tx);
+        }
+        ok = ok && oy < p.cOH && ox < p.cOW;
+        ra[j] = ok ? *reinterpret_cast<const float4*>(p.A + (((long long)a_n[j] * p.cOH + oy) * p.cOW + ox) * p.cO + o)
+                   : zero4();
+      }
+    }
+    // ---------------- B ----------------
+    if constexpr (BMODE == 0) {
+      const int k = kbase + 4 * b_kc;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int row = n0 + b_r0 + 32 * j;
+        const int valid = (row < p.N) ? min(4, max(0, p.K - k)) : 0;
+        rb[j] = valid ? ldg4(p.B + (long long)row * p.ldb + k, valid) : zero4();
+      }
+    } else if constexpr (BMODE == 1) {
+      const int ncol = n0 + 4 * b_mc;
+      const int vn = min(4, max(0, p.N - ncol));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int k = kbase + b_k0 + B_KSTEP * j;
+        rb[j] = (k < p.K && vn) ? ldg4(p.B + (long long)k * p.ldb + ncol, vn) : zero4();
+      }
+    } else if constexpr (BMODE == 2) {  // weight (O, KH, KW, C) read as [k = tap*O + o][n = c]
+      const int ncol = n0 + 4 * b_mc;
+      const int vn = min(4, max(0, p.N - ncol));
+      const int taps = p.cKH * p.cKW;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int k = kbase + b_k0 + B_KSTEP * j;
+        if (k < p.K && vn) {
+          const int tap = k / p.cO, o = k - tap * p.cO;
+          rb[j] = ldg4(p.B + ((long long)o * taps + tap) * p.cC + ncol, vn);
+        } else rb[j] = zero4();
+      }
+    } else {  // BMODE == 3: wgrad im2col; k = output position, n = tap*C + c
+      const int ncol = n0 + 4 * b_mc;
+      const bool nok = ncol < p.N;
+      const int tap = nok ? ncol / p.cC : 0;
+      const int c = ncol - tap * p.cC;
+      const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int k = kbase + b_k0 + B_KSTEP * j;
+        bool ok = nok && k < p.K;
+        float4 v = zero4();
+        if (ok) {
+          const int ox = k % p.cOW;
+          const int tq = k / p.cOW;
+          const int oy = tq % p.cOH;
+          const int n = tq / p.cOH;
+          const int iy = oy * p.cStride - p.cPad + kh, ix = ox * p.cStride - p.cPad + kw;
+          if (iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW)
+            v = *reinterpret_cast<const float4*>(p.B + (((long long)n * p.cH + iy) * p.cW + ix) * p.cC + c);
+        }
+        rb[j] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&]() {
+    if constexpr (A_KC) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        *reinterpret_cast<float4*>(&As[(a_r0 + 32 * j) * A_LD + 4 * a_kc]) = ra[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        *reinterpret_cast<float4*>(&As[(a_k0 + A_KSTEP * j) * A_LD + 4 * a_mc]) = ra[j];
+    }
+    if constexpr (B_KC) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        *reinterpret_cast<float4*>(&Bs[(b_r0 + 32 * j) * B_LD + 4 * b_kc]) = rb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        *reinterpret_cast<float4*>(&Bs[(b_k0 + B_KSTEP * j) * B_LD + 4 * b_mc]) = rb[j];
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  load_tiles(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < kt_end) load_tiles(kt + 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float af[TI][4], bf[TJ][4];
+      const int kq = 8 * g + 4 * lh;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int row = wm * WTM + i * 32 + l31;
+        if constexpr (A_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(&As[row * A_LD + kq]);
+          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) af[i][s] = As[(kq + s) * A_LD + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = wn * WTN + j * 32 + l31;
+        if constexpr (B_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(&Bs[col * B_LD + kq]);
+          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(kq + s) * B_LD + col];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  uint64_t seed = 0, step = 0;
+  const bool drop = p.drop_thresh != 0;
+  if (drop) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  const bool atomic = p.split_k > 1;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + l31;
+      if (col >= p.N) continue;
+      const float sc = p.scale ? p.scale[col] : 1.f;
+      const float bi = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        float* cp = p.C + (long long)row * p.ldc + col;
+        if (atomic) { atomicAdd(cp, v); continue; }
+        v = v * sc + bi;
+        if (p.residual) v += p.residual[(long long)row * p.ldr + col];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (drop) v = cape_keep(seed, step, p.rng_stream, (uint64_t)row * (uint64_t)p.N + col, p.drop_thresh) ? v * p.inv_keep : 0.f;
+        if (p.accumulate) v += *cp;
+        *cp = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+int launch_mode(const GemmP& p, int a_mode, int b_mode, dim3 grid, hipStream_t s) {
+#define CASE(AM, BM_)                                                                      \
+  if (a_mode == AM && b_mode == BM_) {                                                     \
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_>), grid, dim3(256), 0, s, p);          \
+    return 0;                                                                              \
+  }
+  CASE(0, 0) CASE(2, 0) CASE(0, 1) CASE(3, 2) CASE(1, 1) CASE(1, 3)
+#undef CASE
+  return cape_set_error("cape_gemm_f32: unsupported (a_mode=%d, b_mode=%d)", a_mode, b_mode);
+}
+
+}  // namespace
+
+extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
+  CAPE_REQUIRE(d != nullptr, "cape_gemm_f32: null descriptor");
+  CAPE_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "cape_gemm_f32: negative size");
+  if (d->M == 0 || d->N == 0) return 0;
+  CAPE_REQUIRE(d->A && d->B && d->C, "cape_gemm_f32: null operand");
+  CAPE_REQUIRE(d->split_k >= 1, "cape_gemm_f32: split_k must be >= 1");
+  if (d->split_k > 1)
+    CAPE_REQUIRE(!d->scale && !d->bias && !d->residual && !d->relu && d->dropout_p == 0.f,
+                 "cape_gemm_f32: split_k > 1 allows no epilogue op besides accumulation");
+  if (d->a_mode == 2 || d->a_mode == 3 || d->b_mode == 2 || d->b_mode == 3) {
+    CAPE_REQUIRE(d->cC % 4 == 0 && d->cO % 4 == 0, "cape_gemm_f32: conv channels must be multiples of 4 (C=%d, O=%d)", d->cC, d->cO);
+    CAPE_REQUIRE(d->cStride >= 1 && d->cKH >= 1 && d->cKW >= 1, "cape_gemm_f32: bad conv geometry");
+    const long long taps = (long long)d->cKH * d->cKW;
+    if (d->a_mode == 2) CAPE_REQUIRE(d->K == taps * d->cC && d->M == (long long)d->cN * d->cOH * d->cOW, "cape_gemm_f32: conv-fwd shape mismatch");
+    if (d->a_mode == 3) CAPE_REQUIRE(d->K == taps * d->cO && d->M == (long long)d->cN * d->cH * d->cW && d->N == d->cC, "cape_gemm_f32: conv-dgrad shape mismatch");
+    if (d->b_mode == 3) CAPE_REQUIRE(d->N == taps * d->cC && d->K == (long long)d->cN * d->cOH * d->cOW && d->M == d->cO, "cape_gemm_f32: conv-wgrad shape mismatch");
+    CAPE_REQUIRE((reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->B) & 15) == 0,
+                 "cape_gemm_f32: conv operands must be 16-byte aligned");
+  }
+  if (d->dropout_p > 0.f) CAPE_REQUIRE(d->rng_state != nullptr && d->dropout_p < 1.f, "cape_gemm_f32: dropout needs rng_state and p < 1");
+
+  GemmP p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.B = d->B; p.ldb = d->ldb; p.C = d->C; p.ldc = d->ldc;
+  p.cN = d->cN; p.cH = d->cH; p.cW = d->cW; p.cC = d->cC; p.cKH = d->cKH; p.cKW = d->cKW;
+  p.cStride = d->cStride; p.cPad = d->cPad; p.cOH = d->cOH; p.cOW = d->cOW; p.cO = d->cO;
+  p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
+  p.relu = d->relu; p.accumulate = d->accumulate; p.split_k = d->split_k;
+  p.drop_thresh = d->dropout_p > 0.f ? cape_drop_threshold(d->dropout_p) : 0u;
+  p.inv_keep = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
+  p.rng_state = d->rng_state; p.rng_stream = d->rng_stream;
+
+  // tile choice: 128x128 when it still gives >= ~2 tiles per CU (256 CUs), else 64x64
+  const long long t128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->split_k;
+  const bool big = t128 >= 512 && d->N >= 96;
+  const int BMv = big ? 128 : 64;
+  p.tilesM = (d->M + BMv - 1) / BMv;
+  p.tilesN = (d->N + BMv - 1) / BMv;
+  const long long ntiles = (long long)p.tilesM * p.tilesN;
+  CAPE_REQUIRE(ntiles < (1ll << 31), "cape_gemm_f32: too many tiles");
+  dim3 grid((unsigned)ntiles, (unsigned)d->split_k);
+  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, grid, as_stream(stream))
+               : launch_mode<64, 64>(p, d->a_mode, d->b_mode, grid, as_stream(stream));
+  if (rc) return rc;
+  CAPE_LAUNCH_CHECK("cape_gemm_f32");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums: out[n] (+)= sum_m X[m][n].  grid (ceil(N/64), row splits); one column per lane,
+// 4 waves of a block stride over rows; partials combined through LDS then one atomic per column.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_kernel(const float* X, long long ldx, int M, int N, float* out,
+                                                      int rows_per_block) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + w; r < r1; r += 4) s += X[(long long)r * ldx + col];
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && col < N) atomicAdd(&out[col], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+
+extern "C" int cape_colsum_f32(const float* X, long long ldx, int M, int N, float* out, int accumulate,
+                               cape_stream_t stream) {
+  CAPE_REQUIRE(X && out && M >= 0 && N > 0, "cape_colsum_f32: bad arguments");
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, as_stream(stream));
+    if (e != hipSuccess) return cape_set_error("cape_colsum_f32: memset: %s", hipGetErrorString(e));
+  }
+  if (M == 0) return 0;
+  const int gx = (N + 63) / 64;
+  int splits = (M + 255) / 256;
+  const int max_splits = (2048 + gx - 1) / gx;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int rpb = (M + splits - 1) / splits;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, splits), dim3(256), 0, as_stream(stream), X, ldx, M, N, out, rpb);
+  CAPE_LAUNCH_CHECK("cape_colsum_f32");
+  return 0;
+}

@@ -1,0 +1,161 @@
+// support.hip -- geometric support encoder pieces that are not plain GEMM / LayerNorm / attention:
+// coordinate embedding + sine position encodings, adjacency construction, GCN aggregation.
+// The graphs are tiny (P <= 100 keypoints x 256 channels): one block per graph, adjacency in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXP = 100;   // PositionalEncoding1D max_len (geometric_support_encoder.py:98-102)
+
+// h = relu(coords @ W0^T + b0) ; pe = [sine(y) | sine(x)] + pe1d[p]
+__global__ void support_embed_fwd_kernel(const float* coords, const float* W0, const float* b0, const float* pe1d,
+                                         const float* dim_t, float* h, float* pe, int P, int C) {
+  const long long r = blockIdx.x;        // row = n*P + p
+  const int p = (int)(r % P);
+  const float x = coords[r * 2 + 0], y = coords[r * 2 + 1];
+  const int half = C >> 1;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float v = x * W0[c * 2 + 0] + y * W0[c * 2 + 1] + b0[c];
+    h[r * C + c] = fmaxf(v, 0.f);
+    const int k = c < half ? c : c - half;
+    const float e = (c < half ? y : x) * 6.28318530718f / dim_t[k];
+    pe[r * C + c] = ((k & 1) ? cosf(e) : sinf(e)) + pe1d[p * C + c];
+  }
+}
+
+__global__ void support_embed_bwd_kernel(const float* d_h, const float* h, const float* coords, float* dW0, float* db0,
+                                         long long R, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float gx = 0.f, gy = 0.f, gb = 0.f;
+  for (long long r = 0; r < R; ++r) {
+    const float g = h[r * C + c] > 0.f ? d_h[r * C + c] : 0.f;
+    gx += g * coords[r * 2 + 0];
+    gy += g * coords[r * 2 + 1];
+    gb += g;
+  }
+  dW0[c * 2 + 0] += gx;
+  dW0[c * 2 + 1] += gy;
+  db0[c] += gb;
+}
+
+__global__ void adjacency_kernel(const int* edges, const int* edge_start, const uint8_t* mask, float* adj, int P) {
+  extern __shared__ float a[];           // P*P
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < P * P; i += blockDim.x) a[i] = 0.f;
+  __syncthreads();
+  for (int e = edge_start[n] + threadIdx.x; e < edge_start[n + 1]; e += blockDim.x) {
+    int i = edges[2 * e], j = edges[2 * e + 1];
+    if (i < P && j < P) {                // graph_utils.py:59-60 ; negative indices wrap like torch indexing
+      if (i < 0) i += P;
+      if (j < 0) j += P;
+      if (i >= 0 && j >= 0) a[i * P + j] = 1.f;
+    }
+  }
+  __syncthreads();
+  const uint8_t* m = mask + (long long)n * P;
+  float* o0 = adj + (long long)n * 2 * P * P;
+  float* o1 = o0 + P * P;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const float ki = m[i] ? 0.f : 1.f;
+    float rs = 0.f;
+    for (int j = 0; j < P; ++j) {
+      const float v = fmaxf(a[i * P + j], a[j * P + i]) * ki * (m[j] ? 0.f : 1.f);
+      rs += v;
+    }
+    for (int j = 0; j < P; ++j) {
+      const float v = fmaxf(a[i * P + j], a[j * P + i]) * ki * (m[j] ? 0.f : 1.f);
+      o1[i * P + j] = rs > 0.f ? v / rs : 0.f;         // nan_to_num(0/0) = 0
+      o0[i * P + j] = (i == j) ? ki : 0.f;
+    }
+  }
+}
+
+// out[n,w,c] = relu( adj0[w,w]*y[n,w,c] + sum_v adj1[v,w]*y[n,v,C+c] )
+__global__ void gcn_fwd_kernel(const float* y, const float* adj, float* out, int P, int C) {
+  extern __shared__ float a[];           // 2*P*P
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * P * P; i += blockDim.x) a[i] = adj[(long long)n * 2 * P * P + i];
+  __syncthreads();
+  const float* yn = y + (long long)n * P * 2 * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int w = 0; w < P; ++w) {
+      float s = a[w * P + w] * yn[(long long)w * 2 * C + c];
+      for (int v = 0; v < P; ++v) s += a[P * P + v * P + w] * yn[(long long)v * 2 * C + C + c];
+      out[((long long)n * P + w) * C + c] = fmaxf(s, 0.f);
+    }
+  }
+}
+
+__global__ void gcn_bwd_kernel(const float* d_out, const float* out, const float* adj, float* d_y, int P, int C) {
+  extern __shared__ float a[];
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * P * P; i += blockDim.x) a[i] = adj[(long long)n * 2 * P * P + i];
+  __syncthreads();
+  const float* gn = d_out + (long long)n * P * C;
+  const float* on = out + (long long)n * P * C;
+  float* dyn = d_y + (long long)n * P * 2 * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int v = 0; v < P; ++v) {
+      const float gv = on[(long long)v * C + c] > 0.f ? gn[(long long)v * C + c] : 0.f;
+      dyn[(long long)v * 2 * C + c] = a[v * P + v] * gv;
+      float s = 0.f;
+      for (int w = 0; w < P; ++w) {
+        const float gw = on[(long long)w * C + c] > 0.f ? gn[(long long)w * C + c] : 0.f;
+        s += a[P * P + v * P + w] * gw;
+      }
+      dyn[(long long)v * 2 * C + C + c] = s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cape_support_embed_fwd(const float* coords, const float* W0, const float* b0, const float* pe1d,
+                                      const float* dim_t, float* h, float* pe, int N, int P, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(coords && W0 && b0 && pe1d && dim_t && h && pe, "cape_support_embed_fwd: null pointer");
+  CAPE_REQUIRE(C == 256 && P >= 1 && P <= MAXP, "cape_support_embed_fwd: C must be 256 and 1 <= P <= %d", MAXP);
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(support_embed_fwd_kernel, dim3((unsigned)((long long)N * P)), dim3(256), 0, as_stream(stream), coords,
+                     W0, b0, pe1d, dim_t, h, pe, P, C);
+  CAPE_LAUNCH_CHECK("cape_support_embed_fwd");
+  return 0;
+}
+
+extern "C" int cape_support_embed_bwd(const float* d_h, const float* h, const float* coords, float* dW0, float* db0, int N,
+                                      int P, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(d_h && h && coords && dW0 && db0, "cape_support_embed_bwd: null pointer");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(support_embed_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), d_h, h, coords, dW0, db0,
+                     (long long)N * P, C);
+  CAPE_LAUNCH_CHECK("cape_support_embed_bwd");
+  return 0;
+}
+
+extern "C" int cape_adjacency(const int* edges, const int* edge_start, const uint8_t* mask, float* adj, int N, int P,
+                              cape_stream_t stream) {
+  CAPE_REQUIRE(edge_start && mask && adj && P >= 1 && P <= MAXP, "cape_adjacency: bad arguments");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(adjacency_kernel, dim3(N), dim3(128), sizeof(float) * P * P, as_stream(stream), edges, edge_start, mask,
+                     adj, P);
+  CAPE_LAUNCH_CHECK("cape_adjacency");
+  return 0;
+}
+
+extern "C" int cape_gcn_aggregate_fwd(const float* y, const float* adj, float* out, int N, int P, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(y && adj && out && P >= 1 && P <= MAXP, "cape_gcn_aggregate_fwd: bad arguments");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(gcn_fwd_kernel, dim3(N), dim3(256), sizeof(float) * 2 * P * P, as_stream(stream), y, adj, out, P, C);
+  CAPE_LAUNCH_CHECK("cape_gcn_aggregate_fwd");
+  return 0;
+}
+
+extern "C" int cape_gcn_aggregate_bwd(const float* d_out, const float* out, const float* adj, float* d_y, int N, int P, int C,
+                                      cape_stream_t stream) {
+  CAPE_REQUIRE(d_out && out && adj && d_y && P >= 1 && P <= MAXP, "cape_gcn_aggregate_bwd: bad arguments");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(gcn_bwd_kernel, dim3(N), dim3(256), sizeof(float) * 2 * P * P, as_stream(stream), d_out, out, adj, d_y, P,
+                     C);
+  CAPE_LAUNCH_CHECK("cape_gcn_aggregate_bwd");
+  return 0;
+}

@@ -1,0 +1,104 @@
+"""ctypes binding of libcape_hip.so (C ABI declared in include/cape_hip.h).
+
+Fails loudly: a missing / unloadable library raises ImportError at import time; a kernel entry
+point that returns nonzero raises RuntimeError with `cape_last_error()`.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_uint32, c_uint64, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CAPE_HIP_LIB", os.path.join(_HERE, "..", "csrc", "libcape_hip.so"))
+LIB_PATH = os.path.abspath(LIB_PATH)
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"libcape_hip.so not found at {LIB_PATH}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C category-agnostic-pose-estimation_amd/csrc`).  There is no CPU fallback.")
+try:
+    _lib = ctypes.CDLL(LIB_PATH)
+except OSError as e:  # pragma: no cover
+    raise ImportError(f"cannot load {LIB_PATH}: {e}") from e
+
+_lib.cape_last_error.restype = c_char_p
+_lib.cape_abi_version.restype = c_int
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int), ("N", c_int), ("K", c_int), ("a_mode", c_int), ("b_mode", c_int),
+        ("A", c_void_p), ("lda", c_longlong), ("B", c_void_p), ("ldb", c_longlong), ("C", c_void_p), ("ldc", c_longlong),
+        ("cN", c_int), ("cH", c_int), ("cW", c_int), ("cC", c_int), ("cKH", c_int), ("cKW", c_int),
+        ("cStride", c_int), ("cPad", c_int), ("cOH", c_int), ("cOW", c_int), ("cO", c_int),
+        ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_longlong),
+        ("relu", c_int), ("accumulate", c_int), ("split_k", c_int), ("dropout_p", c_float),
+        ("rng_state", c_void_p), ("rng_stream", c_uint32),
+    ]
+
+
+P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
+_SIGS = {
+    "cape_rng_advance": [P, P],
+    "cape_gemm_f32": [POINTER(GemmDesc), P],
+    "cape_colsum_f32": [P, LL, I, I, P, I, P],
+    "cape_add_layernorm_fwd": [P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
+    "cape_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
+    "cape_groupnorm_fwd": [P, P, P, P, LL, P, P, I, I, I, I, P],
+    "cape_groupnorm_bwd": [P, LL, P, P, P, P, P, P, P, I, I, I, I, P],
+    "cape_msda_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "cape_msda_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "cape_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
+    "cape_attn_bwd": [P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
+    "cape_add_f32": [P, P, P, LL, P],
+    "cape_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
+    "cape_bn_fold": [P, P, P, P, F, P, P, I, P],
+    "cape_maxpool3x3s2_nhwc": [P, P, I, I, I, I, P],
+    "cape_bn_relu_bwd": [P, P, P, P, P, LL, I, I, P],
+    "cape_relu_drop_bwd": [P, P, P, LL, F, P],
+    "cape_pos_sine_level": [P, P, P, P, LL, I, I, I, I, P],
+    "cape_token_embed_fwd": [P, P, P, P, P, P, P, P, P, P, LL, I, I, P],
+    "cape_token_embed_bwd": [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, P],
+    "cape_query_sine_fwd": [P, P, P, LL, P],
+    "cape_query_sine_bwd": [P, P, P, P, I, LL, P],
+    "cape_refine_fwd": [P, P, P, LL, P],
+    "cape_refine_bwd": [P, P, P, P, P, I, LL, P],
+    "cape_sigmoid_fwd": [P, P, LL, P],
+    "cape_sigmoid_bwd": [P, P, P, I, LL, P],
+    "cape_ref_scale_fwd": [P, P, P, LL, I, I, P],
+    "cape_ref_scale_bwd": [P, P, P, I, LL, I, I, P],
+    "cape_support_embed_fwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "cape_support_embed_bwd": [P, P, P, P, P, I, I, I, P],
+    "cape_adjacency": [P, P, P, P, I, I, P],
+    "cape_gcn_aggregate_fwd": [P, P, P, I, I, I, P],
+    "cape_gcn_aggregate_bwd": [P, P, P, P, I, I, I, P],
+    "cape_zero_rows": [P, P, LL, I, P],
+    "cape_loss_fwd_bwd": [P, P, P, P, P, P, F, F, F, P, P, P, P, I, LL, P],
+    "cape_sumsq": [P, LL, P, P],
+    "cape_adamw_step": [P, P, P, P, LL, F, F, F, F, F, F, P, P, P],
+    "cape_step_increment": [P, P],
+    "cape_decode_next_tokens": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+}
+EXPORTS = ["cape_last_error", "cape_abi_version"] + list(_SIGS)
+
+for _name, _args in _SIGS.items():
+    _fn = getattr(_lib, _name)      # AttributeError here = header/library mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = c_int
+
+
+def last_error() -> str:
+    return _lib.cape_last_error().decode()
+
+
+def abi_version() -> int:
+    return _lib.cape_abi_version()
+
+
+def call(name, *args):
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {last_error()}")
+
+
+def raw():
+    return _lib

@@ -1,0 +1,497 @@
+"""Raw (non-autograd) launchers: torch tensors in, HIP kernels of libcape_hip.so out.
+
+torch is used for device memory and the current stream only.  Every function checks device,
+dtype and layout on the host before handing raw pointers to the kernels (a kernel fault can take the
+whole GPU node down), and raises if the library reports an error.  No CPU path exists.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib
+
+_F32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, name, dtype=_F32, contiguous=True):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live on the GPU (no CPU fallback in cape_amd)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+
+
+# ------------------------------------------------------------------------------------------------
+# RNG state (device uint64[2] = seed, step) kept as an int64 tensor
+# ------------------------------------------------------------------------------------------------
+class RngState:
+    def __init__(self, seed, device):
+        self.t = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+    def advance(self):
+        lib.call("cape_rng_advance", _p(self.t), _stream())
+
+    @property
+    def ptr(self):
+        return _p(self.t)
+
+
+_stream_counter = [0]
+
+
+def new_stream_id():
+    """Distinct dropout stream id per call site instance."""
+    _stream_counter[0] += 1
+    return _stream_counter[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+def pick_split_k(M, N, K):
+    """Enough tiles to fill 256 CUs about twice; each split keeps >= 8 k-tiles of 32."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    ktiles = (K + 31) // 32
+    want = max(1, 512 // max(tiles, 1))
+    return int(max(1, min(want, ktiles // 8 if ktiles >= 16 else 1, 64)))
+
+
+def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
+         ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None):
+    for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
+        _chk(t, "gemm." + n, contiguous=False)
+    d = lib.GemmDesc()
+    d.M, d.N, d.K, d.a_mode, d.b_mode = M, N, K, a_mode, b_mode
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.lda = lda if lda is not None else (K if a_mode == 0 else M)
+    d.ldb = ldb if ldb is not None else (K if b_mode == 0 else N)
+    d.ldc = ldc if ldc is not None else N
+    if conv is not None:
+        (d.cN, d.cH, d.cW, d.cC, d.cKH, d.cKW, d.cStride, d.cPad, d.cOH, d.cOW, d.cO) = conv
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.ldr = ldr if ldr is not None else N
+    d.relu, d.accumulate, d.split_k = int(relu), int(accumulate), int(split_k)
+    d.dropout_p = float(dropout_p)
+    d.rng_state = rng.t.data_ptr() if (rng is not None and dropout_p > 0) else None
+    d.rng_stream = rng_stream
+    # host-side extent checks (dense modes)
+    if a_mode == 0 and M > 0:
+        assert A.numel() >= (M - 1) * d.lda + K, "gemm: A too small"
+    if a_mode == 1 and K > 0:
+        assert A.numel() >= (K - 1) * d.lda + M, "gemm: A^T too small"
+    if b_mode == 0 and N > 0:
+        assert B.numel() >= (N - 1) * d.ldb + K, "gemm: B too small"
+    if b_mode == 1 and K > 0:
+        assert B.numel() >= (K - 1) * d.ldb + N, "gemm: B too small"
+    if M > 0:
+        assert C.numel() >= (M - 1) * d.ldc + N, "gemm: C too small"
+    if residual is not None:
+        assert residual.numel() >= (M - 1) * d.ldr + N, "gemm: residual too small"
+    if bias is not None:
+        assert bias.numel() >= N
+    if scale is not None:
+        assert scale.numel() >= N
+    lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
+
+
+def colsum(X, M, N, out, ldx=None, accumulate=True):
+    _chk(X, "colsum.X", contiguous=False)
+    _chk(out, "colsum.out")
+    ldx = N if ldx is None else ldx
+    assert M == 0 or X.numel() >= (M - 1) * ldx + N
+    assert out.numel() >= N
+    lib.call("cape_colsum_f32", _p(X), ldx, M, N, _p(out), int(accumulate), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+def add_layernorm_fwd(x, y, gamma, beta, pos=None, dropout_p=0.0, rng=None, rng_stream=0):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    for t, n in ((x, "x"), (y, "y"), (gamma, "gamma"), (beta, "beta"), (pos, "pos")):
+        _chk(t, "ln." + n)
+    if y is not None:
+        assert y.shape == x.shape
+    if pos is not None:
+        assert pos.numel() == x.numel()
+    out = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=_F32, device=x.device)
+    rstd = torch.empty(rows, dtype=_F32, device=x.device)
+    out_pos = torch.empty_like(x) if pos is not None else None
+    lib.call("cape_add_layernorm_fwd", _p(x), _p(y), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), _p(pos),
+             _p(out_pos), rows, C, float(dropout_p), rng.ptr if (rng is not None and dropout_p > 0) else None,
+             rng_stream, _stream())
+    return out, mean, rstd, out_pos
+
+
+def add_layernorm_bwd(d_out, d_out_pos, x, y, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, rng=None, rng_stream=0):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    for t, n in ((d_out, "d_out"), (d_out_pos, "d_out_pos"), (x, "x"), (y, "y"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk(t, "ln_bwd." + n)
+    d_x = torch.empty_like(x)
+    d_y = torch.empty_like(x) if (y is not None and dropout_p > 0) else None
+    lib.call("cape_add_layernorm_bwd", _p(d_out), _p(d_out_pos), _p(x), _p(y), _p(gamma), _p(mean), _p(rstd), _p(d_x),
+             _p(d_y), _p(dgamma), _p(dbeta), rows, C, float(dropout_p),
+             rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+    return d_x, (d_y if d_y is not None else d_x)
+
+
+def groupnorm_fwd(x, gamma, beta, out, out_image_stride, N, HW, C, G=32):
+    for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta")):
+        _chk(t, "gn." + n)
+    _chk(out, "gn.out", contiguous=False)
+    assert x.numel() == N * HW * C
+    mean = torch.empty(N * G, dtype=_F32, device=x.device)
+    rstd = torch.empty(N * G, dtype=_F32, device=x.device)
+    lib.call("cape_groupnorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), out_image_stride, _p(mean), _p(rstd), N, HW, C, G,
+             _stream())
+    return mean, rstd
+
+
+def groupnorm_bwd(d_out, d_out_image_stride, x, gamma, mean, rstd, dgamma, dbeta, N, HW, C, G=32):
+    _chk(d_out, "gn_bwd.d_out", contiguous=False)
+    d_x = torch.empty_like(x)
+    lib.call("cape_groupnorm_bwd", _p(d_out), d_out_image_stride, _p(x), _p(gamma), _p(mean), _p(rstd), _p(d_x),
+             _p(dgamma), _p(dbeta), N, HW, C, G, _stream())
+    return d_x
+
+
+# ------------------------------------------------------------------------------------------------
+# MSDA
+# ------------------------------------------------------------------------------------------------
+class LevelGeometry:
+    """Host-side level table: shapes [(H, W)...], start offsets, S."""
+
+    def __init__(self, shapes):
+        self.shapes = [(int(h), int(w)) for h, w in shapes]
+        self.L = len(self.shapes)
+        starts, s = [], 0
+        for h, w in self.shapes:
+            starts.append(s)
+            s += h * w
+        self.S = s
+        self.starts = starts
+        self._shapes_c = (ctypes.c_int * (2 * self.L))(*[v for hw in self.shapes for v in hw])
+        self._starts_c = (ctypes.c_int * self.L)(*starts)
+
+
+def msda_fwd(value, offw, ref, geo, N, Lq, P=4):
+    for t, n in ((value, "value"), (offw, "offw"), (ref, "ref")):
+        _chk(t, "msda." + n)
+    assert value.numel() == N * geo.S * 256 and offw.numel() == N * Lq * 8 * geo.L * P * 3
+    assert ref.numel() == N * Lq * geo.L * 2
+    out = torch.empty(N, Lq, 256, dtype=_F32, device=value.device)
+    lib.call("cape_msda_fwd", _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(out), N, geo.S, Lq, geo.L, P,
+             _stream())
+    return out
+
+
+def msda_bwd(d_out, value, offw, ref, geo, N, Lq, P=4, need_ref_grad=True):
+    _chk(d_out, "msda_bwd.d_out")
+    d_value = torch.zeros_like(value)
+    d_offw = torch.empty_like(offw)
+    d_ref = torch.zeros_like(ref) if need_ref_grad else None
+    lib.call("cape_msda_bwd", _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
+             _p(d_offw), _p(d_ref), N, geo.S, Lq, geo.L, P, _stream())
+    return d_value, d_offw, d_ref
+
+
+# ------------------------------------------------------------------------------------------------
+# attention core
+# ------------------------------------------------------------------------------------------------
+def _ld(t):
+    assert t.stride(-1) == 1
+    return t.stride(-2)
+
+
+def attn_fwd(Q, K, V, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0, rng=None, rng_stream=0):
+    """Q (N,Lq,*) K,V (N,Lk,*) as (possibly strided) views whose last dim holds H*32 head channels."""
+    for t, n in ((Q, "Q"), (K, "K"), (V, "V")):
+        _chk(t, "attn." + n, contiguous=False)
+        assert t.stride(0) == t.shape[1] * t.stride(1), "attn: batch stride must be L*ld"
+    if kpm is not None:
+        _chk(kpm, "attn.kpm", dtype=torch.uint8)
+        assert kpm.numel() == N * Lk
+    O = torch.empty(N, Lq, H * 32, dtype=_F32, device=Q.device)
+    lse = torch.empty(N, H, Lq, dtype=_F32, device=Q.device)
+    lib.call("cape_attn_fwd", _p(Q), _p(K), _p(V), _p(O), _p(lse), _ld(Q), _ld(K), _ld(V), H * 32, N, H, Lq, Lk,
+             float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
+             rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+    return O, lse
+
+
+def attn_bwd(dO, Q, K, V, O, lse, dQ, dK, dV, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0,
+             rng=None, rng_stream=0):
+    _chk(dO, "attn_bwd.dO")
+    for t in (dQ, dK, dV):
+        _chk(t, "attn_bwd.grad", contiguous=False)
+    assert _ld(dQ) == _ld(Q) and _ld(dK) == _ld(K) and _ld(dV) == _ld(V)
+    lib.call("cape_attn_bwd", _p(dO), _p(Q), _p(K), _p(V), _p(O), _p(lse), _p(dQ), _p(dK), _p(dV), _ld(Q), _ld(K), _ld(V),
+             H * 32, N, H, Lq, Lk, float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
+             rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise and small ops
+# ------------------------------------------------------------------------------------------------
+def add(a, b):
+    _chk(a, "add.a"); _chk(b, "add.b")
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    lib.call("cape_add_f32", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def nchw_to_nhwc(x, Cp):
+    _chk(x, "nchw_to_nhwc.x")
+    N, C, H, W = x.shape
+    out = torch.empty(N, H, W, Cp, dtype=_F32, device=x.device)
+    lib.call("cape_nchw_to_nhwc", _p(x), _p(out), N, C, H, W, Cp, _stream())
+    return out
+
+
+def bn_fold(w, b, rm, rv, eps=1e-5):
+    for t in (w, b, rm, rv):
+        _chk(t, "bn_fold")
+    scale, shift = torch.empty_like(w), torch.empty_like(w)
+    lib.call("cape_bn_fold", _p(w), _p(b), _p(rm), _p(rv), float(eps), _p(scale), _p(shift), w.numel(), _stream())
+    return scale, shift
+
+
+def maxpool3x3s2(x):
+    _chk(x, "maxpool.x")
+    N, H, W, C = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(N, OH, OW, C, dtype=_F32, device=x.device)
+    lib.call("cape_maxpool3x3s2_nhwc", _p(x), _p(out), N, H, W, C, _stream())
+    return out
+
+
+def bn_relu_bwd(dy, y, scale, relu, want_res):
+    _chk(dy, "bn_relu_bwd.dy"); _chk(y, "bn_relu_bwd.y"); _chk(scale, "bn_relu_bwd.scale")
+    C = dy.shape[-1]
+    rows = dy.numel() // C
+    d_pre = torch.empty_like(dy)
+    d_res = torch.empty_like(dy) if want_res else None
+    lib.call("cape_bn_relu_bwd", _p(dy), _p(y), _p(scale), _p(d_pre), _p(d_res), rows, C, int(relu), _stream())
+    return d_pre, d_res
+
+
+def relu_drop_bwd(dh, h, inv_keep):
+    _chk(dh, "relu_drop_bwd.dh"); _chk(h, "relu_drop_bwd.h")
+    out = torch.empty_like(dh)
+    lib.call("cape_relu_drop_bwd", _p(dh), _p(h), _p(out), dh.numel(), float(inv_keep), _stream())
+    return out
+
+
+_DIMT = {}
+
+
+def dim_t(device):
+    """10000 ** (2*(k//2)/128), the exact torch expression of the reference (position_encoding.py:33-34)."""
+    key = str(device)
+    if key not in _DIMT:
+        d = torch.arange(128, dtype=torch.float32)
+        _DIMT[key] = (10000 ** (2 * (d // 2) / 128)).to(device)
+    return _DIMT[key]
+
+
+def pos_sine_level(mask_u8, level_embed_l, out, out_image_stride, N, h, w, C=256):
+    _chk(mask_u8, "pos.mask", dtype=torch.uint8)
+    _chk(level_embed_l, "pos.level_embed")
+    _chk(out, "pos.out", contiguous=False)
+    assert mask_u8.numel() == N * h * w
+    lib.call("cape_pos_sine_level", _p(mask_u8), _p(level_embed_l), _p(dim_t(out.device)), _p(out), out_image_stride, N, h,
+             w, C, _stream())
+
+
+def token_embed_fwd(table, seqs, deltas):
+    """seqs = (s11, s21, s12, s22) int64 (R,), deltas = (dx1, dx2, dy1, dy2) float (R,)."""
+    _chk(table, "tok.table")
+    R = seqs[0].numel()
+    for s in seqs:
+        _chk(s, "tok.seq", dtype=torch.int64)
+        assert s.numel() == R
+    for d in deltas:
+        _chk(d, "tok.delta")
+        assert d.numel() == R
+    V, C = table.shape
+    out = torch.empty(R, C, dtype=_F32, device=table.device)
+    lib.call("cape_token_embed_fwd", _p(table), *[_p(s) for s in seqs], *[_p(d) for d in deltas], _p(out), R, C, V, _stream())
+    return out
+
+
+def token_embed_bwd(d_out, seqs, deltas, d_table, pad_idx):
+    _chk(d_out, "tok_bwd.d_out"); _chk(d_table, "tok_bwd.d_table")
+    V, C = d_table.shape
+    R = seqs[0].numel()
+    lib.call("cape_token_embed_bwd", _p(d_out), *[_p(s) for s in seqs], *[_p(d) for d in deltas], _p(d_table), R, C, V,
+             int(pad_idx), _stream())
+
+
+def query_sine_fwd(ref):
+    _chk(ref, "qsine.ref")
+    R = ref.numel() // 2
+    out = torch.empty(R, 256, dtype=_F32, device=ref.device)
+    lib.call("cape_query_sine_fwd", _p(ref), _p(dim_t(ref.device)), _p(out), R, _stream())
+    return out
+
+
+def query_sine_bwd(d_out, ref):
+    _chk(d_out, "qsine_bwd.d_out")
+    d_ref = torch.empty_like(ref)
+    lib.call("cape_query_sine_bwd", _p(d_out), _p(ref), _p(dim_t(ref.device)), _p(d_ref), 0, ref.numel() // 2, _stream())
+    return d_ref
+
+
+def refine_fwd(delta, ref):
+    _chk(delta, "refine.delta"); _chk(ref, "refine.ref")
+    assert delta.shape == ref.shape
+    out = torch.empty_like(ref)
+    lib.call("cape_refine_fwd", _p(delta), _p(ref), _p(out), ref.numel(), _stream())
+    return out
+
+
+def refine_bwd(d_new, new_ref, ref):
+    _chk(d_new, "refine_bwd.d_new")
+    d_delta, d_ref = torch.empty_like(ref), torch.empty_like(ref)
+    lib.call("cape_refine_bwd", _p(d_new), _p(new_ref), _p(ref), _p(d_delta), _p(d_ref), 0, ref.numel(), _stream())
+    return d_delta, d_ref
+
+
+def sigmoid_fwd(x):
+    _chk(x, "sigmoid.x")
+    y = torch.empty_like(x)
+    lib.call("cape_sigmoid_fwd", _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def sigmoid_bwd(dy, y):
+    _chk(dy, "sigmoid_bwd.dy")
+    dx = torch.empty_like(y)
+    lib.call("cape_sigmoid_bwd", _p(dy), _p(y), _p(dx), 0, y.numel(), _stream())
+    return dx
+
+
+def ref_scale_fwd(ref, valid_ratios, rows_per_image, L):
+    _chk(ref, "ref_scale.ref"); _chk(valid_ratios, "ref_scale.vr")
+    R = ref.numel() // 2
+    out = torch.empty(R, L, 2, dtype=_F32, device=ref.device)
+    lib.call("cape_ref_scale_fwd", _p(ref), _p(valid_ratios), _p(out), R, rows_per_image, L, _stream())
+    return out
+
+
+def ref_scale_bwd(d_in, valid_ratios, rows_per_image, L):
+    _chk(d_in, "ref_scale_bwd.d_in")
+    R = d_in.numel() // (2 * L)
+    d_ref = torch.empty(R, 2, dtype=_F32, device=d_in.device)
+    lib.call("cape_ref_scale_bwd", _p(d_in), _p(valid_ratios), _p(d_ref), 0, R, rows_per_image, L, _stream())
+    return d_ref
+
+
+def support_embed_fwd(coords, W0, b0, pe1d, N, P, C=256):
+    for t in (coords, W0, b0, pe1d):
+        _chk(t, "support_embed")
+    assert coords.numel() == N * P * 2 and W0.numel() == C * 2 and pe1d.numel() >= P * C
+    h = torch.empty(N * P, C, dtype=_F32, device=coords.device)
+    pe = torch.empty(N * P, C, dtype=_F32, device=coords.device)
+    lib.call("cape_support_embed_fwd", _p(coords), _p(W0), _p(b0), _p(pe1d), _p(dim_t(coords.device)), _p(h), _p(pe), N, P,
+             C, _stream())
+    return h, pe
+
+
+def support_embed_bwd(d_h, h, coords, dW0, db0, N, P, C=256):
+    for t in (d_h, h, coords, dW0, db0):
+        _chk(t, "support_embed_bwd")
+    lib.call("cape_support_embed_bwd", _p(d_h), _p(h), _p(coords), _p(dW0), _p(db0), N, P, C, _stream())
+
+
+def adjacency(edges_i32, edge_start_i32, mask_u8, N, P):
+    _chk(edges_i32, "adj.edges", dtype=torch.int32)
+    _chk(edge_start_i32, "adj.start", dtype=torch.int32)
+    _chk(mask_u8, "adj.mask", dtype=torch.uint8)
+    assert edge_start_i32.numel() == N + 1 and mask_u8.numel() == N * P
+    adj = torch.empty(N, 2, P, P, dtype=_F32, device=mask_u8.device)
+    lib.call("cape_adjacency", _p(edges_i32), _p(edge_start_i32), _p(mask_u8), _p(adj), N, P, _stream())
+    return adj
+
+
+def gcn_aggregate_fwd(y, adj, N, P, C=256):
+    _chk(y, "gcn.y"); _chk(adj, "gcn.adj")
+    assert y.numel() == N * P * 2 * C and adj.numel() == N * 2 * P * P
+    out = torch.empty(N, P, C, dtype=_F32, device=y.device)
+    lib.call("cape_gcn_aggregate_fwd", _p(y), _p(adj), _p(out), N, P, C, _stream())
+    return out
+
+
+def gcn_aggregate_bwd(d_out, out, adj, N, P, C=256):
+    _chk(d_out, "gcn_bwd.d_out")
+    d_y = torch.empty(N, P, 2 * C, dtype=_F32, device=out.device)
+    lib.call("cape_gcn_aggregate_bwd", _p(d_out), _p(out), _p(adj), _p(d_y), N, P, C, _stream())
+    return d_y
+
+
+def zero_rows(x, rowmask_u8):
+    _chk(x, "zero_rows.x"); _chk(rowmask_u8, "zero_rows.mask", dtype=torch.uint8)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    assert rowmask_u8.numel() == rows
+    lib.call("cape_zero_rows", _p(x), _p(rowmask_u8), rows, C, _stream())
+
+
+def loss_fwd_bwd(logits, coords, labels, vis_u8, target, class_w, w_ce, w_l1, loss_scale):
+    """logits (NL,R,3) coords (NL,R,2) -> losses (2*NL), total (1), d_logits, d_coords."""
+    _chk(logits, "loss.logits"); _chk(coords, "loss.coords"); _chk(target, "loss.target"); _chk(class_w, "loss.cw")
+    _chk(labels, "loss.labels", dtype=torch.int64); _chk(vis_u8, "loss.vis", dtype=torch.uint8)
+    NL = logits.shape[0]
+    R = logits.numel() // (NL * 3)
+    assert coords.numel() == NL * R * 2 and labels.numel() == R and vis_u8.numel() == R and target.numel() == R * 2
+    losses = torch.empty(2 * NL, dtype=_F32, device=logits.device)
+    total = torch.empty(1, dtype=_F32, device=logits.device)
+    d_logits, d_coords = torch.empty_like(logits), torch.empty_like(coords)
+    lib.call("cape_loss_fwd_bwd", _p(logits), _p(coords), _p(labels), _p(vis_u8), _p(target), _p(class_w), float(w_ce),
+             float(w_l1), float(loss_scale), _p(losses), _p(total), _p(d_logits), _p(d_coords), NL, R, _stream())
+    return losses, total, d_logits, d_coords
+
+
+def sumsq(g, out):
+    _chk(g, "sumsq.g"); _chk(out, "sumsq.out")
+    lib.call("cape_sumsq", _p(g), g.numel(), _p(out), _stream())
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, max_norm, sumsq_t, step_t):
+    for t in (p, g, m, v):
+        _chk(t, "adamw")
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    _chk(step_t, "adamw.step", dtype=torch.int64)
+    lib.call("cape_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+             float(wd), float(max_norm), _p(sumsq_t), _p(step_t), _stream())
+
+
+def step_increment(step_t):
+    lib.call("cape_step_increment", _p(step_t), _stream())
+
+
+def decode_next_tokens(cls_logits, reg, unfinished_i32, tok_i64, delta, step_i32, N, num_bins, min_len, eos, sep, pad):
+    _chk(cls_logits, "next.cls"); _chk(reg, "next.reg"); _chk(delta, "next.delta")
+    _chk(unfinished_i32, "next.unfinished", dtype=torch.int32); _chk(tok_i64, "next.tok", dtype=torch.int64)
+    _chk(step_i32, "next.step", dtype=torch.int32)
+    assert cls_logits.numel() == N * 3 and reg.numel() == N * 2 and tok_i64.numel() == 4 * N and delta.numel() == 4 * N
+    lib.call("cape_decode_next_tokens", _p(cls_logits), _p(reg), _p(unfinished_i32), _p(tok_i64), _p(delta), _p(step_i32), N,
+             num_bins, min_len, eos, sep, pad, _stream())

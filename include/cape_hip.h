@@ -1,0 +1,271 @@
+/* cape_hip.h -- C ABI of libcape_hip.so, the MI355X (gfx950) kernels of the CAPE episodic
+ * training / inference hot path.
+ *
+ * The reference (nkkrnkl/category-agnostic-pose-estimation) is 100 % PyTorch: it has no FFI or
+ * operator-plugin layer.  These entry points are therefore
+ * the boundary a maintainer would bind to *replace the torch expressions cited next to each
+ * function*; INTEGRATION.md shows the ctypes stub for each.  Conventions:
+ *   - plain pointers + sizes only (no torch types); all pointers are DEVICE pointers unless said
+ *     otherwise; all tensors fp32 row-major unless said otherwise;
+ *   - every function enqueues on `stream` and returns immediately: 0 = ok, nonzero = error
+ *     (message via cape_last_error()); no function allocates, frees or synchronises (graph-capturable);
+ *   - no ownership transfer; workspaces are explicit arguments;
+ *   - thread-compatible: the only global is the thread-local error string.
+ */
+#ifndef CAPE_HIP_H
+#define CAPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cape_stream_t; /* hipStream_t */
+
+const char* cape_last_error(void);
+int cape_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * RNG state for dropout: device uint64[2] = {seed, step}.  Masks are a pure function of
+ * (seed, step, stream id, element index) so backward regenerates them; cape_rng_advance bumps `step`
+ * on device (graph-replay safe).  Replaces torch's global Philox generator used by nn.Dropout
+ * (models/deformable_transformer.py:177-183, deformable_transformer_v2.py:286-305).
+ * ---------------------------------------------------------------------------------------------- */
+int cape_rng_advance(uint64_t* rng_state, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM family on fp32 MFMA (v_mfma_f32_32x32x2_f32):  C[M,N] (+)= epi(A[M,K] * B[K,N])
+ *
+ * a_mode: 0 dense A[M][K] (lda)                 -- nn.Linear input, 1x1 stride-1 conv input (NHWC)
+ *         1 dense A stored transposed [K][M]     -- wgrad: A = dY^T
+ *         2 conv-forward im2col gather of an NHWC tensor, k = (kh, kw, c)
+ *         3 conv-dgrad gather of dY (NHWC), k = (kh, kw, o)
+ * b_mode: 0 dense B stored [N][K] (ldb)          -- nn.Linear / conv weight ([O][KH][KW][C] = channels_last)
+ *         1 dense B stored [K][N] (ldb)          -- dgrad of nn.Linear; wgrad's activation operand
+ *         2 conv weight read as [(kh,kw,o)][c]   -- conv dgrad
+ *         3 conv-wgrad im2col gather, k = output position, n = (kh, kw, c)
+ * Epilogue (split_k == 1): v = acc; v = v*scale[n] (opt); v += bias[n] (opt); v += residual[m][n] (opt);
+ *   relu (opt); dropout(p) (opt, applied last); then C = v or C += v (accumulate).
+ * split_k > 1: partial sums are atomically added into C (C must hold the value to accumulate onto);
+ *   no other epilogue op is allowed.
+ * Replaces: F.linear / nn.Conv2d + FrozenBatchNorm2d (+ReLU, +residual) and their autograd
+ *   (models/backbone.py:32-40, torchvision Bottleneck; deformable_transformer.py:95,99-100,113,208;
+ *   deformable_transformer_v2.py:314-318,323-331; roomformer_v2.py:192-201,956-968).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int M, N, K;
+  int a_mode, b_mode;
+  const float* A; long long lda;
+  const float* B; long long ldb;
+  float* C; long long ldc;
+  /* conv geometry for gather modes: input N,H,W,C ; kernel KH,KW,stride,pad ; output OH,OW,O */
+  int cN, cH, cW, cC, cKH, cKW, cStride, cPad, cOH, cOW, cO;
+  const float* scale;      /* [N] or NULL */
+  const float* bias;       /* [N] or NULL */
+  const float* residual;   /* [M][ldr] or NULL */
+  long long ldr;
+  int relu;
+  int accumulate;
+  int split_k;
+  float dropout_p;         /* 0 = off */
+  const uint64_t* rng_state;
+  uint32_t rng_stream;
+} cape_gemm_desc;
+
+int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
+
+/* column sums:  out[n] (+)= sum_m X[m][n]   (bias gradients; level_embed gradient) */
+int cape_colsum_f32(const float* X, long long ldx, int M, int N, float* out, int accumulate, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * out = LayerNorm(x + dropout(y)) * gamma + beta over rows of C (C <= 1024, C % 4 == 0), eps 1e-5.
+ * y may be NULL (plain LayerNorm).  Saves mean/rstd (per row) for backward.  If pos != NULL also writes
+ * out_pos = out + pos (the `with_pos_embed` add, deformable_transformer.py:197).
+ * Replaces `self.normK(src + self.dropoutK(src2))` (deformable_transformer.py:209-210,228-229;
+ * deformable_transformer_v2.py:340-341,356-357,364-365,316-317) and nn.TransformerEncoderLayer's norms.
+ * ---------------------------------------------------------------------------------------------- */
+int cape_add_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,
+                           float* out, float* mean, float* rstd, const float* pos, float* out_pos,
+                           int rows, int C, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
+                           cape_stream_t stream);
+/* backward: given d_out (and optional d_out_pos, added), recomputes s = x + dropout(y) and returns
+ * d_x (= ds) and d_y (= ds * mask / keep); accumulates dgamma/dbeta (+=).  d_y may alias d_x when y == NULL
+ * or dropout_p == 0 (then only d_x is written and d_y must be NULL or equal to d_x). */
+int cape_add_layernorm_bwd(const float* d_out, const float* d_out_pos, const float* x, const float* y,
+                           const float* gamma, const float* mean, const float* rstd,
+                           float* d_x, float* d_y, float* dgamma, float* dbeta,
+                           int rows, int C, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
+                           cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(G groups) over NHWC data x[n][hw][C] -> out written with a per-image row stride so that
+ * the result lands directly inside the flattened multi-level token buffer (N, S, C) at the level's
+ * offset.  eps 1e-5.  Replaces nn.GroupNorm(32, hidden_dim) + flatten(2).transpose(1,2) + cat
+ * (roomformer_v2.py:192-201, deformable_transformer_v2.py:189-200).
+ * ---------------------------------------------------------------------------------------------- */
+int cape_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* out,
+                       long long out_image_stride, float* mean, float* rstd,
+                       int N, int HW, int C, int G, cape_stream_t stream);
+int cape_groupnorm_bwd(const float* d_out, long long d_out_image_stride, const float* x,
+                       const float* gamma, const float* mean, const float* rstd,
+                       float* d_x, float* dgamma, float* dbeta, int N, int HW, int C, int G,
+                       cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention core (fused softmax over L*P logits + bilinear gather + weighted sum).
+ *   value   (N, S, M, D)        D == 32, M == 8
+ *   offw    (N, Lq, 384)  = [ sampling_offsets (M,L,P,2) | attention logits (M,L*P) ] per query
+ *   ref     (N, Lq, L, 2)       normalised reference points
+ *   shapes  int32 [L][2] (H_l, W_l) ; level_start int32 [L]        (host pointers)
+ *   out     (N, Lq, M*D)
+ * Semantics of F.grid_sample(bilinear, zeros padding, align_corners=False) on grid 2*loc-1.
+ * Replaces MSDeformAttn.forward:99-112 + ms_deform_attn_core_pytorch (deformable_transformer.py:115-141).
+ * ---------------------------------------------------------------------------------------------- */
+int cape_msda_fwd(const float* value, const float* offw, const float* ref, const int* shapes,
+                  const int* level_start, float* out, int N, int S, int Lq, int L, int P,
+                  cape_stream_t stream);
+/* backward: d_value must be zero-initialised by the caller (atomically accumulated); d_offw, d_ref written
+ * (d_ref may be NULL). */
+int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
+                  const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
+                  int N, int S, int Lq, int L, int P, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense attention core, heads of 32 channels packed in rows of `ld` floats:
+ *   O[n,i,h,:] = sum_j softmax_j(scale * Q[n,i,h,:].K[n,j,h,:] + mask) (dropped) V[n,j,h,:]
+ * mask_mode 0 none, 1 causal (j <= i + causal_offset), 2 key padding (uint8 kpm[n][Lk], 1 = ignore).
+ * lse (N,H,Lq) saved for backward.  Fully masked rows give NaN exactly like torch softmax(-inf row).
+ * Replaces the core of nn.MultiheadAttention (deformable_transformer_v2.py:339, :352-355;
+ * geometric_support_encoder.py:223-226).
+ * ---------------------------------------------------------------------------------------------- */
+int cape_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse,
+                  long long ldq, long long ldk, long long ldv, long long ldo,
+                  int N, int H, int Lq, int Lk, float scale, int mask_mode, int causal_offset,
+                  const uint8_t* kpm, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
+                  cape_stream_t stream);
+int cape_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* O,
+                  const float* lse, float* dQ, float* dK, float* dV,
+                  long long ldq, long long ldk, long long ldv, long long ldo,
+                  int N, int H, int Lq, int Lk, float scale, int mask_mode, int causal_offset,
+                  const uint8_t* kpm, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
+                  cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / small ops.  `dim_t` = device float[128] temperature table
+ *   10000 ** (2*(k//2)/128) computed by the host with the same torch expression as the reference.
+ * ---------------------------------------------------------------------------------------------- */
+/* out = a + b (n floats, n % 4 == 0 not required) */
+int cape_add_f32(const float* a, const float* b, float* out, long long n, cape_stream_t stream);
+/* NCHW (N,C,H,W) -> NHWC with channel padding to Cp (zeros) */
+int cape_nchw_to_nhwc(const float* x, float* out, int N, int C, int H, int W, int Cp, cape_stream_t stream);
+/* FrozenBatchNorm fold: scale = w * rsqrt(rv + eps), shift = b - rm * scale  (backbone.py:32-40) */
+int cape_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps,
+                 float* scale, float* shift, int C, cape_stream_t stream);
+/* 3x3 stride-2 pad-1 max pool on NHWC */
+int cape_maxpool3x3s2_nhwc(const float* x, float* out, int N, int H, int W, int C, cape_stream_t stream);
+/* backward through y = relu(conv*scale + shift (+res)):  d_pre = dy * (y > 0) * scale[c] ;
+ * d_res = dy * (y > 0) (optional).  relu == 0 skips the mask.  rows x C, C % 4 == 0. */
+int cape_bn_relu_bwd(const float* dy, const float* y, const float* scale, float* d_pre, float* d_res,
+                     long long rows, int C, int relu, cape_stream_t stream);
+/* d_pre = dh * (h > 0) * inv_keep  (backward of relu+dropout fused in a GEMM epilogue) */
+int cape_relu_drop_bwd(const float* dh, const float* h, float* d_pre, long long n, float inv_keep,
+                       cape_stream_t stream);
+/* image sine position embedding + level embedding, written into the flattened (N,S,256) buffer:
+ * models/position_encoding.py:22-40 with normalize=True; mask uint8 (N,h,w) 1 = padded. */
+int cape_pos_sine_level(const uint8_t* mask, const float* level_embed_l, const float* dim_t, float* out,
+                        long long out_image_stride, int N, int h, int w, int C, cape_stream_t stream);
+
+/* 4-corner bilinear token embedding (deformable_transformer_v2.py:984-997):
+ * ids int64 (R) x4, deltas float (R) x4 -> out (R, C) */
+int cape_token_embed_fwd(const float* table, const int64_t* s11, const int64_t* s21, const int64_t* s12,
+                         const int64_t* s22, const float* dx1, const float* dx2, const float* dy1,
+                         const float* dy2, float* out, long long R, int C, int vocab, cape_stream_t stream);
+int cape_token_embed_bwd(const float* d_out, const int64_t* s11, const int64_t* s21, const int64_t* s12,
+                         const int64_t* s22, const float* dx1, const float* dx2, const float* dy1,
+                         const float* dy2, float* d_table, long long R, int C, int vocab, int pad_idx,
+                         cape_stream_t stream);
+
+/* decoder query sine embedding (deformable_transformer_v2.py:1005-1018): ref (R,2) -> out (R,256),
+ * x-block then y-block, 128 features per axis */
+int cape_query_sine_fwd(const float* ref, const float* dim_t, float* out, long long R, cape_stream_t stream);
+int cape_query_sine_bwd(const float* d_out, const float* ref, const float* dim_t, float* d_ref, int accumulate, long long R,
+                        cape_stream_t stream);
+
+/* iterative refinement (deformable_transformer_v2.py:1096-1102, util/misc.py:436-440):
+ * new_ref = sigmoid(delta + inverse_sigmoid(ref)), eps 1e-5 ; n elements */
+int cape_refine_fwd(const float* delta, const float* ref, float* new_ref, long long n, cape_stream_t stream);
+/* d_delta = d_new * s(1-s) ; d_ref (+)= d_new * s(1-s) * d inverse_sigmoid(ref)/d ref */
+int cape_refine_bwd(const float* d_new, const float* new_ref, const float* ref, float* d_delta,
+                    float* d_ref, int accumulate_ref, long long n, cape_stream_t stream);
+/* y = sigmoid(x) and backward dx (+)= dy * y (1-y) */
+int cape_sigmoid_fwd(const float* x, float* y, long long n, cape_stream_t stream);
+int cape_sigmoid_bwd(const float* dy, const float* y, float* dx, int accumulate, long long n,
+                     cape_stream_t stream);
+/* ref_in[r][l][:] = ref[r][:] * valid_ratio[n(r)][l][:]  (R rows, rows_per_image rows per image) and bwd */
+int cape_ref_scale_fwd(const float* ref, const float* valid_ratios, float* ref_in, long long R,
+                       int rows_per_image, int L, cape_stream_t stream);
+int cape_ref_scale_bwd(const float* d_ref_in, const float* valid_ratios, float* d_ref, int accumulate,
+                       long long R, int rows_per_image, int L, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geometric support encoder pieces (models/geometric_support_encoder.py:163-192, graph_utils.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* h = relu(coords @ W0^T + b0) (R,256) ; pe = sine2d(coords) + pe1d[p]  (R,256) ; R = N*P rows */
+int cape_support_embed_fwd(const float* coords, const float* W0, const float* b0, const float* pe1d,
+                           const float* dim_t, float* h, float* pe, int N, int P, int C, cape_stream_t stream);
+/* dW0 (+)= dh^T coords masked by relu ; db0 (+)= ... ; (coords carry no gradient) */
+int cape_support_embed_bwd(const float* d_h, const float* h, const float* coords, float* dW0, float* db0,
+                           int N, int P, int C, cape_stream_t stream);
+/* adjacency (N,2,P,P) from an edge list: edges int32 (E_total,2), edge_start int32 (N+1), mask uint8 (N,P)
+ * (1 = ignore).  graph_utils.py:46-80 */
+int cape_adjacency(const int* edges, const int* edge_start, const uint8_t* mask, float* adj, int N, int P,
+                   cape_stream_t stream);
+/* GCN aggregate: out[n,w,c] = relu( sum_k sum_v adj[n,k,v,w] * y[n,v,k*C+c] )  (graph_utils.py:157-186) */
+int cape_gcn_aggregate_fwd(const float* y, const float* adj, float* out, int N, int P, int C,
+                           cape_stream_t stream);
+/* d_y[n,v,k*C+c] = sum_w adj[n,k,v,w] * d_out[n,w,c] * (out[n,w,c] > 0) */
+int cape_gcn_aggregate_bwd(const float* d_out, const float* out, const float* adj, float* d_y, int N,
+                           int P, int C, cape_stream_t stream);
+/* rows with rowmask[r] != 0 are set to zero (n floats per row) */
+int cape_zero_rows(float* x, const uint8_t* rowmask, long long rows, int C, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss (models/cape_losses.py:71-163, roomformer_v2.py:915-953), all NL decoder layers at once.
+ *   logits (NL, R, 3), coords (NL, R, 2), labels int64 (R), vis uint8 (R), target (R, 2)
+ *   class_w float[3]; w_ce, w_l1 loss weights; loss_scale multiplies the gradients (1/accum steps)
+ * Outputs: losses float[2*NL] = {ce_l, l1_l}_l (unweighted), total float[1] (weighted sum),
+ *          d_logits / d_coords = d total*loss_scale / d input.
+ * ---------------------------------------------------------------------------------------------- */
+int cape_loss_fwd_bwd(const float* logits, const float* coords, const int64_t* labels, const uint8_t* vis,
+                      const float* target, const float* class_w, float w_ce, float w_l1, float loss_scale,
+                      float* losses, float* total, float* d_logits, float* d_coords, int NL, long long R,
+                      cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer over flat arenas (train_cape_episodic.py:527-538, engine_cape.py:240-258):
+ *   cape_sumsq: out[0] (+)= sum g^2 ; cape_adamw_step: clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6))
+ *   read from device, torch.optim.AdamW semantics (decoupled weight decay, bias correction with `step`
+ *   read from device step_count[0], incremented by cape_step_increment).
+ * ---------------------------------------------------------------------------------------------- */
+int cape_sumsq(const float* g, long long n, float* out, cape_stream_t stream);
+int cape_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float max_norm, const float* sumsq,
+                    const int64_t* step_count, cape_stream_t stream);
+int cape_step_increment(int64_t* step_count, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Autoregressive decode bookkeeping on device (roomformer_v2.py:521-598): from the step's class logits
+ * (N,3) and coordinates (N,2) produce the next step's 4 token ids + 4 deltas and update the unfinished
+ * flags; also appends logits/coords to the per-step output buffers.
+ * ---------------------------------------------------------------------------------------------- */
+int cape_decode_next_tokens(const float* cls_logits, const float* reg, int32_t* unfinished,
+                            int64_t* tok /* (4,N): 11,12,21,22 */, float* delta /* (4,N): x1,x2,y1,y2 */,
+                            const int32_t* step /* device scalar */, int N, int num_bins, int min_len,
+                            int eos_id, int sep_id, int pad_id, cape_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPE_HIP_H */

@@ -1,0 +1,505 @@
+"""GPU parity tests of every HIP kernel behind the C ABI against CPU restatements
+(oracle/cape_ref.py where the op exists there, plain torch fp32 CPU math otherwise).
+Tolerances: fp32 arithmetic with a different summation order -> 1e-4 relative to the tensor scale
+unless stated; integer/index outputs exact."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import cape_amd  # noqa: F401
+    from cape_amd.hip import ops
+from oracle import cape_ref
+
+DEV = "cuda"
+CFG = cape_ref.Cfg()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(got, ref, tol=1e-4, name=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs().max().item() if got.numel() else 0.0
+    scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
+    assert err <= tol * scale, f"{name}: max err {err:.3e} (scale {scale:.3e})"
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 70, 256), (128, 128, 32), (1000, 256, 1024), (640, 3, 256), (64, 384, 256),
+                                   (50, 256, 2), (33, 2, 36), (5000, 1024, 256), (17, 256, 256)])
+def test_gemm_nt_epilogues(M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, sc = rnd(M, N, seed=4), rnd(N, seed=5).abs() + 0.5
+    xd, wd, bd, rd, sd = (t.to(DEV) for t in (x, w, b, res, sc))
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(xd, wd, out, M, N, K, bias=bd)
+    close(out, F.linear(x, w, b), name="bias")
+    ops.gemm(xd, wd, out, M, N, K, bias=bd, scale=sd, residual=rd, relu=True)
+    close(out, F.relu(x @ w.t() * sc + b + res), name="scale+bias+res+relu")
+    out2 = out.clone()
+    ops.gemm(xd, wd, out2, M, N, K, accumulate=True)
+    close(out2, out.cpu() + x @ w.t(), name="accumulate")
+    if K >= 512:
+        out3 = torch.zeros(M, N, device=DEV)
+        ops.gemm(xd, wd, out3, M, N, K, split_k=4)
+        close(out3, x @ w.t(), name="split_k")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 70), (640, 256, 3), (1000, 1024, 256), (77, 36, 2)])
+def test_gemm_nn_dgrad(M, N, K):
+    dy, w = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(dy.to(DEV), w.to(DEV), out, M, N, K, a_mode=0, b_mode=1)
+    close(out, dy @ w, name="nn")
+
+
+@pytest.mark.parametrize("Mo,Ni,Kr", [(70, 256, 300), (3, 256, 640), (1024, 256, 3000), (256, 2, 100)])
+def test_gemm_tn_wgrad(Mo, Ni, Kr):
+    dy, x = rnd(Kr, Mo, seed=1), rnd(Kr, Ni, seed=2)
+    out = torch.zeros(Mo, Ni, device=DEV)
+    ops.gemm(dy.to(DEV), x.to(DEV), out, Mo, Ni, Kr, a_mode=1, b_mode=1, accumulate=True, split_k=ops.pick_split_k(Mo, Ni, Kr))
+    close(out, dy.t() @ x, tol=2e-4, name="tn")
+
+
+def _conv_case(N, H, W, C, O, k, stride, pad, seed=0):
+    x = rnd(N, C, H, W, seed=seed)
+    w = rnd(O, C, k, k, seed=seed + 1, scale=(C * k * k) ** -0.5)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    geom = (N, H, W, C, k, k, stride, pad, OH, OW, O)
+    return x, w, geom, OH, OW
+
+
+@pytest.mark.parametrize("N,H,W,C,O,k,stride,pad", [(2, 16, 16, 64, 64, 3, 1, 1), (2, 17, 15, 32, 48, 3, 2, 1),
+                                                    (3, 16, 16, 64, 128, 1, 2, 0), (2, 32, 32, 4, 64, 7, 2, 3),
+                                                    (2, 8, 8, 128, 256, 1, 1, 0), (1, 8, 8, 256, 256, 3, 2, 1)])
+def test_conv_fwd_dgrad_wgrad(N, H, W, C, O, k, stride, pad):
+    x, w, geom, OH, OW = _conv_case(N, H, W, C, O, k, stride, pad)
+    sc, sh = rnd(O, seed=7).abs() + 0.5, rnd(O, seed=8)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y_ref = F.conv2d(x, w, stride=stride, padding=pad)
+    z_ref = F.relu(y_ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    g = rnd(*y_ref.shape, seed=9)
+    y_ref.backward(g)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)                 # NHWC
+    wn = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)                 # (O,KH,KW,C)
+    M, K = N * OH * OW, k * k * C
+    out = torch.empty(M, O, device=DEV)
+    ops.gemm(xn, wn, out, M, O, K, a_mode=2, b_mode=0, conv=geom, scale=sc.to(DEV), bias=sh.to(DEV), relu=True)
+    close(out.view(N, OH, OW, O).permute(0, 3, 1, 2), z_ref, name="conv fwd")
+    gn = g.permute(0, 2, 3, 1).contiguous().to(DEV)
+    # dgrad
+    dx = torch.empty(N * H * W, C, device=DEV)
+    ops.gemm(gn, wn, dx, N * H * W, C, k * k * O, a_mode=3, b_mode=2, conv=geom)
+    close(dx.view(N, H, W, C).permute(0, 3, 1, 2), x.grad, tol=2e-4, name="conv dgrad")
+    # wgrad
+    dw = torch.zeros(O, k * k * C, device=DEV)
+    ops.gemm(gn, xn, dw, O, k * k * C, M, a_mode=1, b_mode=3, lda=O, conv=geom, accumulate=True,
+             split_k=ops.pick_split_k(O, k * k * C, M))
+    close(dw.view(O, k, k, C).permute(0, 3, 1, 2), w.grad, tol=2e-4, name="conv wgrad")
+
+
+def test_gemm_dropout_epilogue_statistics_and_replay():
+    M, N, K = 512, 256, 64
+    x, w = torch.ones(M, K, device=DEV), torch.ones(N, K, device=DEV)
+    rng = ops.RngState(1234, DEV)
+    a, b = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.gemm(x, w, a, M, N, K, dropout_p=0.1, rng=rng, rng_stream=5)
+    ops.gemm(x, w, b, M, N, K, dropout_p=0.1, rng=rng, rng_stream=5)
+    assert torch.equal(a, b)                                   # same (seed, step, stream) -> same mask
+    frac = (a == 0).float().mean().item()
+    assert abs(frac - 0.1) < 0.01
+    assert torch.allclose(a[a != 0], torch.full_like(a[a != 0], K / 0.9))
+    rng.advance()
+    ops.gemm(x, w, b, M, N, K, dropout_p=0.1, rng=rng, rng_stream=5)
+    assert not torch.equal(a, b)
+
+
+def test_colsum():
+    x = rnd(1000, 300, seed=3)
+    out = torch.ones(300, device=DEV)
+    ops.colsum(x.to(DEV), 1000, 300, out, accumulate=True)
+    close(out, 1 + x.sum(0), tol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,C", [(37, 256), (1000, 256), (9, 1024), (5, 64)])
+def test_add_layernorm_fwd_bwd(rows, C):
+    x, y, g, b, pos = rnd(rows, C, seed=1), rnd(rows, C, seed=2), rnd(C, seed=3) + 1, rnd(C, seed=4), rnd(rows, C, seed=5)
+    x.requires_grad_(True); y.requires_grad_(True); g.requires_grad_(True); b.requires_grad_(True)
+    ref = F.layer_norm(x + y, (C,), g, b, 1e-5)
+    go, gp = rnd(rows, C, seed=6), rnd(rows, C, seed=7)
+    (ref * go + (ref + pos) * gp).sum().backward()
+    xd, yd, gd, bd, pd = (t.detach().to(DEV) for t in (x, y, g, b, pos))
+    out, mean, rstd, out_pos = ops.add_layernorm_fwd(xd, yd, gd, bd, pos=pd)
+    close(out, ref, name="ln out")
+    close(out_pos, ref + pos, name="ln out_pos")
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx, dy = ops.add_layernorm_bwd(go.to(DEV), gp.to(DEV), xd, yd, gd, mean, rstd, dg, db)
+    close(dx, x.grad, tol=2e-4, name="ln dx")
+    close(dy, y.grad, tol=2e-4, name="ln dy")
+    close(dg, g.grad, tol=2e-4, name="ln dgamma")
+    close(db, b.grad, tol=2e-4, name="ln dbeta")
+
+
+def test_add_layernorm_dropout_consistency():
+    rows, C = 64, 256
+    x, y = torch.zeros(rows, C, device=DEV), torch.ones(rows, C, device=DEV)
+    g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    rng = ops.RngState(7, DEV)
+    out, mean, rstd, _ = ops.add_layernorm_fwd(x, y, g, b, dropout_p=0.25, rng=rng, rng_stream=3)
+    kept = out > 0                                             # s in {0, 1/0.75}: kept elements are above the row mean
+    frac = 1 - kept.float().mean().item()
+    assert abs(frac - 0.25) < 0.03
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx, dy = ops.add_layernorm_bwd(torch.randn(rows, C, device=DEV), None, x, y, g, mean, rstd, dg, db, dropout_p=0.25,
+                                   rng=rng, rng_stream=3)
+    assert torch.equal(dy == 0, ~kept) or ((dy == 0) & kept).float().mean() < 1e-3
+    assert torch.allclose(dy[kept], dx[kept] / 0.75)
+
+
+@pytest.mark.parametrize("N,HW,C", [(3, 64, 256), (2, 1024, 256), (2, 1, 256)])
+def test_groupnorm_fwd_bwd(N, HW, C):
+    x = rnd(N, C, HW, seed=1)
+    g, b = rnd(C, seed=2) + 1, rnd(C, seed=3)
+    x.requires_grad_(True); g.requires_grad_(True); b.requires_grad_(True)
+    ref = F.group_norm(x, 32, g, b, 1e-5)
+    go = rnd(N, C, HW, seed=4)
+    (ref * go).sum().backward()
+    xd = x.detach().permute(0, 2, 1).contiguous().to(DEV)                    # (N,HW,C)
+    S = HW + 5
+    out = torch.zeros(N, S, C, device=DEV)
+    mean, rstd = ops.groupnorm_fwd(xd, g.detach().to(DEV), b.detach().to(DEV), out[:, 3:], S * C, N, HW, C)
+    close(out[:, 3:3 + HW], ref.permute(0, 2, 1), name="gn out")
+    assert float(out[:, :3].abs().sum()) == 0 and float(out[:, 3 + HW:].abs().sum()) == 0
+    dfull = torch.zeros(N, S, C, device=DEV)
+    dfull[:, 3:3 + HW] = go.permute(0, 2, 1).to(DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.groupnorm_bwd(dfull[:, 3:], S * C, xd, g.detach().to(DEV), mean, rstd, dg, db, N, HW, C)
+    close(dx, x.grad.permute(0, 2, 1), tol=2e-4, name="gn dx")
+    close(dg, g.grad, tol=2e-4, name="gn dgamma")
+    close(db, b.grad, tol=2e-4, name="gn dbeta")
+
+
+# ------------------------------------------------------------------------------------------------
+# MSDA
+# ------------------------------------------------------------------------------------------------
+def _msda_inputs(N, Lq, shapes, seed):
+    S = sum(h * w for h, w in shapes)
+    value = rnd(N, S, 8, 32, seed=seed)
+    offw = torch.cat([rnd(N, Lq, 256, seed=seed + 1, scale=1.5), rnd(N, Lq, 128, seed=seed + 2)], -1).contiguous()
+    ref = torch.rand(N, Lq, len(shapes), 2, generator=torch.Generator().manual_seed(seed + 3)) * 1.2 - 0.1
+    return value, offw, ref
+
+
+def _msda_ref(value, offw, ref, shapes):
+    N, Lq = offw.shape[:2]
+    L = len(shapes)
+    off = offw[..., :256].reshape(N, Lq, 8, L, 4, 2)
+    aw = F.softmax(offw[..., 256:].reshape(N, Lq, 8, 16), -1).view(N, Lq, 8, L, 4)
+    norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    return cape_ref.msda_core(value, shapes, loc, aw)
+
+
+@pytest.mark.parametrize("N,Lq,shapes", [(2, 37, [(8, 8), (4, 4), (2, 2), (1, 1)]), (9, 5, [(6, 10), (3, 5), (2, 3), (1, 2)]),
+                                         (1, 1360, [(32, 32), (16, 16), (8, 8), (4, 4)])])
+def test_msda_fwd_bwd(N, Lq, shapes):
+    value, offw, ref = _msda_inputs(N, Lq, shapes, 11)
+    value.requires_grad_(True); offw.requires_grad_(True); ref.requires_grad_(True)
+    out_ref = _msda_ref(value, offw, ref, shapes)
+    go = rnd(N, Lq, 256, seed=5)
+    out_ref.backward(go)
+    geo = ops.LevelGeometry(shapes)
+    vd, od, rd = value.detach().to(DEV), offw.detach().to(DEV), ref.detach().to(DEV)
+    out = ops.msda_fwd(vd, od, rd, geo, N, Lq)
+    close(out, out_ref, name="msda fwd")
+    dv, do, dr = ops.msda_bwd(go.to(DEV), vd, od, rd, geo, N, Lq)
+    close(dv, value.grad, tol=3e-4, name="msda d_value")
+    close(do, offw.grad, tol=3e-4, name="msda d_offw")
+    close(dr, ref.grad, tol=3e-4, name="msda d_ref")
+
+
+def test_msda_core_against_reference_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "msda_core.npz"))
+    shapes = [tuple(int(v) for v in s) for s in d["shapes"]]
+    value, loc, aw = torch.from_numpy(d["value"]), torch.from_numpy(d["loc"]), torch.from_numpy(d["aw"])
+    N, Lq = loc.shape[:2]
+    # express (loc, softmaxed aw) through the kernel's inputs: ref = 0, offsets = loc * (W,H), logits = log(aw)
+    norm = torch.tensor([[w, h] for (h, w) in shapes], dtype=torch.float32)
+    off = (loc * norm[None, None, None, :, None, :]).reshape(N, Lq, 256)
+    offw = torch.cat([off, aw.clamp_min(1e-30).log().reshape(N, Lq, 128)], -1).contiguous()
+    ref = torch.zeros(N, Lq, 4, 2)
+    out = ops.msda_fwd(value.to(DEV), offw.to(DEV), ref.to(DEV), ops.LevelGeometry(shapes), N, Lq)
+    close(out, torch.from_numpy(d["out"]), name="msda golden")
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, scale, mask):
+    N, Lq, C = q.shape
+    H = C // 32
+    qh, kh, vh = (t.view(N, -1, H, 32).transpose(1, 2) for t in (q, k, v))
+    s = (qh * scale) @ kh.transpose(-1, -2)
+    if mask is not None:
+        s = s + mask
+    return (F.softmax(s, -1) @ vh).transpose(1, 2).reshape(N, Lq, C)
+
+
+@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 70, 17, 2), (2, 9, 9, 0), (2, 1, 37, 0), (1, 130, 130, 1)])
+def test_attention_fwd_bwd(N, Lq, Lk, mode):
+    H = 8
+    big_q, big_k, big_v = rnd(N, Lq, 768, seed=1), rnd(N, Lk, 768, seed=2), rnd(N, Lk, 768, seed=3)
+    q, k, v = big_q[..., :256], big_k[..., 256:512], big_v[..., 512:]          # strided views (ld = 768)
+    qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+    mask, kpm = None, None
+    if mode == 1:
+        mask = torch.triu(torch.full((Lq, Lk), float("-inf")), diagonal=1)
+    if mode == 2:
+        kpm = torch.zeros(N, Lk, dtype=torch.bool)
+        kpm[:, 3] = True; kpm[0, 10:] = True
+        mask = torch.zeros(N, 1, 1, Lk).masked_fill(kpm[:, None, None, :], float("-inf"))
+    scale = 32 ** -0.5
+    ref = _attn_ref(qc, kc, vc, scale, mask)
+    go = rnd(N, Lq, 256, seed=4)
+    ref.backward(go)
+    Qd, Kd, Vd = big_q.to(DEV), big_k.to(DEV), big_v.to(DEV)
+    qd, kd, vd = Qd[..., :256], Kd[..., 256:512], Vd[..., 512:]
+    kpm_d = kpm.to(torch.uint8).to(DEV) if kpm is not None else None
+    O, lse = ops.attn_fwd(qd, kd, vd, N, H, Lq, Lk, scale, mask_mode=mode, kpm=kpm_d)
+    close(O, ref, name="attn fwd")
+    dQ, dK, dV = torch.zeros_like(Qd), torch.zeros_like(Kd), torch.zeros_like(Vd)
+    ops.attn_bwd(go.to(DEV), qd, kd, vd, O, lse, dQ[..., :256], dK[..., 256:512], dV[..., 512:], N, H, Lq, Lk, scale,
+                 mask_mode=mode, kpm=kpm_d)
+    close(dQ[..., :256], qc.grad, tol=2e-4, name="attn dQ")
+    close(dK[..., 256:512], kc.grad, tol=2e-4, name="attn dK")
+    close(dV[..., 512:], vc.grad, tol=2e-4, name="attn dV")
+    assert float(dQ[..., 256:].abs().sum()) == 0
+
+
+def test_attention_dropout_fwd_bwd_consistent():
+    """With dropout the kernel's gradients must be the gradients of its own (masked) forward:
+    finite-difference check of sum(O * G) with respect to V (linear in V -> exact up to rounding)."""
+    N, H, L = 1, 8, 40
+    q, k, v = rnd(N, L, 256, seed=1).to(DEV), rnd(N, L, 256, seed=2).to(DEV), rnd(N, L, 256, seed=3).to(DEV)
+    g = rnd(N, L, 256, seed=4).to(DEV)
+    rng = ops.RngState(99, DEV)
+    O, lse = ops.attn_fwd(q, k, v, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    dQ, dK, dV = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attn_bwd(g, q, k, v, O, lse, dQ, dK, dV, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    dv_dir = rnd(N, L, 256, seed=5).to(DEV)
+    O2, _ = ops.attn_fwd(q, k, v + dv_dir, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    lhs = ((O2 - O) * g).sum().item()
+    rhs = (dV * dv_dir).sum().item()
+    assert abs(lhs - rhs) <= 2e-3 * max(1.0, abs(rhs))
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise / small ops
+# ------------------------------------------------------------------------------------------------
+def test_layout_bn_maxpool_relu_bwd():
+    x = rnd(2, 3, 9, 7, seed=1)
+    out = ops.nchw_to_nhwc(x.to(DEV), 4)
+    close(out[..., :3], x.permute(0, 2, 3, 1))
+    assert float(out[..., 3].abs().sum()) == 0
+    w, b, rm, rv = rnd(64, seed=2) + 1, rnd(64, seed=3), rnd(64, seed=4), rnd(64, seed=5).abs() + 0.5
+    sc, sh = ops.bn_fold(w.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV))
+    s_ref = w * (rv + 1e-5).rsqrt()
+    close(sc, s_ref, tol=1e-6); close(sh, b - rm * s_ref, tol=1e-6)
+    y = rnd(2, 64, 11, 13, seed=6)
+    mp = ops.maxpool3x3s2(y.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close(mp.permute(0, 3, 1, 2), F.max_pool2d(y, 3, 2, 1), tol=0)
+    dy, yy = rnd(50, 64, seed=7), rnd(50, 64, seed=8)
+    d_pre, d_res = ops.bn_relu_bwd(dy.to(DEV), yy.to(DEV), sc, True, True)
+    close(d_res, dy * (yy > 0)); close(d_pre, dy * (yy > 0) * s_ref)
+    close(ops.relu_drop_bwd(dy.to(DEV), yy.to(DEV), 1 / 0.9), dy * (yy > 0) / 0.9)
+    close(ops.add(dy.to(DEV), yy.to(DEV)), dy + yy, tol=0)
+
+
+def test_pos_sine_level():
+    N, h, w = 2, 6, 5
+    mask = torch.zeros(N, h, w, dtype=torch.bool)
+    mask[1, 4:, :] = True; mask[1, :, 3:] = True
+    lvl = rnd(256, seed=1)
+    S = h * w + 4
+    out = torch.zeros(N, S, 256, device=DEV)
+    ops.pos_sine_level(mask.to(torch.uint8).to(DEV), lvl.to(DEV), out[:, 2:], S * 256, N, h, w)
+    ref = cape_ref.position_embedding_sine(mask).reshape(N, h * w, 256) + lvl
+    close(out[:, 2:2 + h * w], ref, tol=2e-6)
+
+
+def test_token_embed_query_sine_refine():
+    R, V, C = 300, 2000, 256
+    tab = rnd(V, C, seed=1); tab[1939] = 0
+    g = torch.Generator().manual_seed(2)
+    seqs = [torch.randint(0, 1940, (R,), generator=g) for _ in range(4)]
+    seqs[0][:5] = 1939
+    deltas = [torch.rand(R, generator=g) for _ in range(4)]
+    t = {"seq11": seqs[0], "seq21": seqs[1], "seq12": seqs[2], "seq22": seqs[3],
+         "delta_x1": deltas[0], "delta_x2": deltas[1], "delta_y1": deltas[2], "delta_y2": deltas[3]}
+    tabg = tab.clone().requires_grad_(True)
+    ref = cape_ref.seq_embed({"base_model.transformer.decoder.token_embed.weight": tabg}, t)
+    go = rnd(R, C, seed=3)
+    ref.backward(go)
+    sd, dd = [s.to(DEV) for s in seqs], [d.to(DEV) for d in deltas]
+    out = ops.token_embed_fwd(tab.to(DEV), sd, dd)
+    close(out, ref, tol=1e-6, name="tok fwd")
+    dt = torch.zeros(V, C, device=DEV)
+    ops.token_embed_bwd(go.to(DEV), sd, dd, dt, 1939)
+    want = tabg.grad.clone(); want[1939] = 0                    # padding_idx row receives no gradient
+    close(dt, want, tol=1e-4, name="tok bwd")
+
+    refp = torch.rand(R, 2, generator=g).requires_grad_(True)
+    qs = cape_ref.query_pos_sine(refp[None])[0]
+    gq = rnd(R, 256, seed=4)
+    qs.backward(gq)
+    close(ops.query_sine_fwd(refp.detach().to(DEV)), qs, tol=2e-6, name="qsine fwd")
+    close(ops.query_sine_bwd(gq.to(DEV), refp.detach().to(DEV)), refp.grad, tol=2e-4, name="qsine bwd")
+
+    r0 = torch.rand(R, 2, generator=g); r0[0, 0] = 0.0; r0[1, 1] = 1.0; r0[2, 0] = 1e-6
+    r0.requires_grad_(True)
+    dl = rnd(R, 2, seed=5).requires_grad_(True)
+    nr = torch.sigmoid(dl + cape_ref.inverse_sigmoid(r0))
+    gn = rnd(R, 2, seed=6)
+    nr.backward(gn)
+    nd = ops.refine_fwd(dl.detach().to(DEV), r0.detach().to(DEV))
+    close(nd, nr, tol=2e-6, name="refine fwd")
+    dd_, dr_ = ops.refine_bwd(gn.to(DEV), nd, r0.detach().to(DEV))
+    close(dd_, dl.grad, tol=1e-5, name="refine d_delta")
+    close(dr_[3:], r0.grad[3:], tol=2e-4, name="refine d_ref")
+    x = rnd(77, seed=7)
+    y = ops.sigmoid_fwd(x.to(DEV))
+    close(y, torch.sigmoid(x), tol=1e-6)
+    close(ops.sigmoid_bwd(torch.ones(77, device=DEV), y), torch.sigmoid(x) * (1 - torch.sigmoid(x)), tol=1e-6)
+    vr = torch.rand(3, 4, 2, generator=g)
+    rr = torch.rand(3 * 10, 2, generator=g)
+    o = ops.ref_scale_fwd(rr.to(DEV), vr.to(DEV), 10, 4)
+    want = rr.view(3, 10, 1, 2) * vr[:, None]
+    close(o, want.reshape(30, 4, 2), tol=1e-6)
+    gi = rnd(30, 4, 2, seed=8)
+    close(ops.ref_scale_bwd(gi.to(DEV), vr.to(DEV), 10, 4), (gi.view(3, 10, 4, 2) * vr[:, None]).sum(2).reshape(30, 2), tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# support encoder pieces
+# ------------------------------------------------------------------------------------------------
+def test_support_embed_adjacency_gcn(golden_dir, proc_sd):
+    d = np.load(os.path.join(golden_dir, "support_encoder.npz"))
+    coords, m = torch.from_numpy(d["coords"]), torch.from_numpy(d["enc_mask"])
+    skel = json.loads(bytes(d["skel_json"]).decode())
+    N, P = coords.shape[:2]
+    sd = proc_sd
+    W0, b0 = sd["support_encoder.coord_mlp.0.weight"], sd["support_encoder.coord_mlp.0.bias"]
+    pe1d = sd["support_encoder.sequence_pos_encoding.pe"][0]
+    h, pe = ops.support_embed_fwd(coords.to(DEV), W0.to(DEV), b0.to(DEV), pe1d.contiguous().to(DEV), N, P)
+    close(h, F.relu(F.linear(coords, W0, b0)).reshape(N * P, 256), tol=1e-6, name="coord mlp0")
+    close(pe, (cape_ref.support_pe_2d(coords) + pe1d[None, :P]).reshape(N * P, 256), tol=2e-6, name="support pe")
+    gh = rnd(N * P, 256, seed=1)
+    dW, db = torch.zeros(256, 2, device=DEV), torch.zeros(256, device=DEV)
+    ops.support_embed_bwd(gh.to(DEV), h, coords.to(DEV), dW, db, N, P)
+    gm = gh * (h.cpu() > 0)
+    close(dW, gm.t() @ coords.reshape(-1, 2), tol=1e-4); close(db, gm.sum(0), tol=1e-4)
+    edges = [e for s in skel for e in s]
+    start = np.cumsum([0] + [len(s) for s in skel]).astype(np.int32)
+    e_t = torch.tensor(edges if edges else [[0, 0]], dtype=torch.int32).to(DEV)
+    adj = ops.adjacency(e_t, torch.from_numpy(start).to(DEV), m.to(torch.uint8).to(DEV), N, P)
+    close(adj, torch.from_numpy(d["adj"]), tol=1e-7, name="adjacency")
+    y = rnd(N, P, 512, seed=2).requires_grad_(True)
+    adj_c = torch.from_numpy(d["adj"])
+    ref = F.relu(torch.einsum("nvkc,nkvw->nwc", y.view(N, P, 2, 256), adj_c))
+    go = rnd(N, P, 256, seed=3)
+    ref.backward(go)
+    out = ops.gcn_aggregate_fwd(y.detach().to(DEV), adj, N, P)
+    close(out, ref, name="gcn fwd")
+    close(ops.gcn_aggregate_bwd(go.to(DEV), out, adj, N, P), y.grad, name="gcn bwd")
+    x = rnd(N * P, 256, seed=4).to(DEV)
+    rm = torch.zeros(N * P, dtype=torch.uint8); rm[P:2 * P] = 1
+    ops.zero_rows(x, rm.to(DEV))
+    assert float(x[P:2 * P].abs().sum()) == 0 and float(x[:P].abs().sum()) > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# loss, optimizer, decode bookkeeping
+# ------------------------------------------------------------------------------------------------
+def test_loss_fwd_bwd():
+    from oracle import synth
+    b = synth.make_batch(5, 3, 2, 64, 9, CFG, n_invisible=(2, 0))
+    t = b["targets"]
+    N, L = t["token_labels"].shape
+    logits = rnd(6, N, L, 3, seed=1).requires_grad_(True)
+    coords = torch.rand(6, N, L, 2, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
+    out = {"pred_logits": logits[5], "pred_coords": coords[5],
+           "aux_outputs": [{"pred_logits": logits[i], "pred_coords": coords[i]} for i in range(5)]}
+    losses, w, total = cape_ref.criterion(out, t, CFG)
+    (total * 0.25).backward()
+    cw = torch.tensor([1.0, 1.0, 20.0])
+    ls, tot, dl, dc = ops.loss_fwd_bwd(logits.detach().to(DEV), coords.detach().to(DEV), t["token_labels"].to(DEV),
+                                       t["visibility_mask"].to(torch.uint8).to(DEV), t["target_seq"].to(DEV), cw.to(DEV),
+                                       1.0, 5.0, 0.25)
+    ls = ls.cpu()
+    names = [f"_{i}" for i in range(5)] + [""]
+    for i, s in enumerate(names):
+        assert abs(ls[2 * i].item() - float(losses["loss_ce" + s])) < 1e-5
+        assert abs(ls[2 * i + 1].item() - float(losses["loss_coords" + s])) < 1e-6
+    assert abs(tot.item() - float(total)) < 1e-4
+    close(dl, logits.grad, tol=1e-6, name="d_logits")
+    close(dc, coords.grad, tol=1e-6, name="d_coords")
+
+
+def test_adamw_matches_torch():
+    n = 10007
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=1e-2)
+    pd, md, vd = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ss = torch.zeros(1, device=DEV)
+    for it in range(3):
+        g = g0 * (it + 1)
+        p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([p], 0.1)
+        opt.step()
+        ss.zero_()
+        gd = g.to(DEV)
+        ops.sumsq(gd, ss)
+        ops.step_increment(step)
+        ops.adamw_step(pd, gd, md, vd, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.1, ss, step)
+    assert abs(math.sqrt(ss.item()) - (g0 * 3).norm().item()) < 1e-2
+    close(pd, p.detach(), tol=1e-6, name="adamw")
+
+
+def test_decode_next_tokens_matches_oracle():
+    N = 64
+    g = torch.Generator().manual_seed(3)
+    for step in (0, 5, 6, 30):
+        logits = torch.randn(N, 3, generator=g)
+        reg = torch.rand(N, 2, generator=g) * 1.1
+        reg[0] = torch.tensor([1.0, 0.0]); reg[1] = torch.tensor([43.0 / 43.0, 0.5])
+        unf = torch.rand(N, generator=g) > 0.2
+        t, dl, unf2 = cape_ref.next_tokens(logits.argmax(-1), reg, unf.clone(), step, CFG)
+        u = unf.to(torch.int32).to(DEV)
+        tok = torch.empty(4, N, dtype=torch.int64, device=DEV)
+        de = torch.empty(4, N, device=DEV)
+        ops.decode_next_tokens(logits.to(DEV), reg.to(DEV), u, tok, de, torch.tensor([step], dtype=torch.int32, device=DEV),
+                               N, 44, 6, CFG.eos, CFG.sep, CFG.pad)
+        for i, k in enumerate(("11", "12", "21", "22")):
+            assert torch.equal(tok[i].cpu(), t[k]), (step, k)
+        for i in range(4):
+            assert torch.equal(de[i].cpu(), dl[i]), (step, i)
+        assert torch.equal(u.cpu().bool(), unf2)
