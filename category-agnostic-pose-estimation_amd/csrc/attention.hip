@@ -17,6 +17,7 @@ constexpr int ROWS = 64;     // rows per block (x 4 lanes)
 
 struct AttnP {
   long long ldq, ldk, ldv, ldo;
+  long long bsq, bsk, bsv, bso;   // batch strides (elements)
   int N, H, Lq, Lk;
   float scale;
   int mask_mode, causal_offset;
@@ -52,15 +53,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
   const int i = blockIdx.x * ROWS + (threadIdx.x >> 2);
-  stage_rows(Ks, K + (long long)n * p.Lk * p.ldk + h * HD, p.ldk, p.Lk);
-  stage_rows(Vs, V + (long long)n * p.Lk * p.ldv + h * HD, p.ldv, p.Lk);
+  stage_rows(Ks, K + (long long)n * p.bsk + h * HD, p.ldk, p.Lk);
+  stage_rows(Vs, V + (long long)n * p.bsv + h * HD, p.ldv, p.Lk);
   __syncthreads();
   const bool live = i < p.Lq;
   float q[8], acc[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) { q[d] = 0.f; acc[d] = 0.f; }
   if (live) {
-    const float* qp = Q + ((long long)n * p.Lq + i) * p.ldq + h * HD + sub * 8;
+    const float* qp = Q + (long long)n * p.bsq + (long long)i * p.ldq + h * HD + sub * 8;
     const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
     q[0] = a.x * p.scale; q[1] = a.y * p.scale; q[2] = a.z * p.scale; q[3] = a.w * p.scale;
     q[4] = b.x * p.scale; q[5] = b.y * p.scale; q[6] = b.z * p.scale; q[7] = b.w * p.scale;
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   }
   if (live) {
     const float inv = 1.f / l;                 // l == 0 (fully masked row) -> NaN like torch
-    float* op = O + ((long long)n * p.Lq + i) * p.ldo + h * HD + sub * 8;
+    float* op = O + (long long)n * p.bso + (long long)i * p.ldo + h * HD + sub * 8;
     *reinterpret_cast<float4*>(op) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
     *reinterpret_cast<float4*>(op + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
     if (sub == 0) lse[((long long)n * p.H + h) * p.Lq + i] = m + __logf(l);
@@ -118,8 +119,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
   const int i = blockIdx.x * ROWS + (threadIdx.x >> 2);
-  stage_rows(Ks, K + (long long)n * p.Lk * p.ldk + h * HD, p.ldk, p.Lk);
-  stage_rows(Vs, V + (long long)n * p.Lk * p.ldv + h * HD, p.ldv, p.Lk);
+  stage_rows(Ks, K + (long long)n * p.bsk + h * HD, p.ldk, p.Lk);
+  stage_rows(Vs, V + (long long)n * p.bsv + h * HD, p.ldv, p.Lk);
   __syncthreads();
   const bool live = i < p.Lq;
   float q[8], go[8], acc[8];
@@ -127,10 +128,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
   for (int d = 0; d < 8; ++d) { q[d] = 0.f; go[d] = 0.f; acc[d] = 0.f; }
   if (live) {
-    const long long ro = (long long)n * p.Lq + i;
-    const float* qp = Q + ro * p.ldq + h * HD + sub * 8;
-    const float* gp = dO + ro * p.ldo + h * HD + sub * 8;
-    const float* op = O + ro * p.ldo + h * HD + sub * 8;
+    const float* qp = Q + (long long)n * p.bsq + (long long)i * p.ldq + h * HD + sub * 8;
+    const float* gp = dO + (long long)n * p.bso + (long long)i * p.ldo + h * HD + sub * 8;
+    const float* op = O + (long long)n * p.bso + (long long)i * p.ldo + h * HD + sub * 8;
 #pragma unroll
     for (int d = 0; d < 8; ++d) { q[d] = qp[d] * p.scale; go[d] = gp[d]; D += gp[d] * op[d]; }
     L = lse[((long long)n * p.H + h) * p.Lq + i];
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     acc[4] += ds * k1.x; acc[5] += ds * k1.y; acc[6] += ds * k1.z; acc[7] += ds * k1.w;
   }
   if (live) {
-    float* dp_ = dQ + ((long long)n * p.Lq + i) * p.ldq + h * HD + sub * 8;
+    float* dp_ = dQ + (long long)n * p.bsq + (long long)i * p.ldq + h * HD + sub * 8;
     *reinterpret_cast<float4*>(dp_) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     *reinterpret_cast<float4*>(dp_ + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
@@ -182,11 +182,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
   const int j = blockIdx.x * ROWS + (threadIdx.x >> 2);
-  stage_rows(Qs, Q + (long long)n * p.Lq * p.ldq + h * HD, p.ldq, p.Lq);
-  stage_rows(Gs, dO + (long long)n * p.Lq * p.ldo + h * HD, p.ldo, p.Lq);
+  stage_rows(Qs, Q + (long long)n * p.bsq + h * HD, p.ldq, p.Lq);
+  stage_rows(Gs, dO + (long long)n * p.bso + h * HD, p.ldo, p.Lq);
   for (int r = threadIdx.x; r < p.Lq; r += blockDim.x) {
-    const float* op = O + ((long long)n * p.Lq + r) * p.ldo + h * HD;
-    const float* gp = dO + ((long long)n * p.Lq + r) * p.ldo + h * HD;
+    const float* op = O + (long long)n * p.bso + (long long)r * p.ldo + h * HD;
+    const float* gp = dO + (long long)n * p.bso + (long long)r * p.ldo + h * HD;
     float d = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; ++c) d += op[c] * gp[c];
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   for (int d = 0; d < 8; ++d) { k[d] = 0.f; v[d] = 0.f; ak[d] = 0.f; av[d] = 0.f; }
   bool keymasked = false;
   if (live) {
-    const float* kp_ = K + ((long long)n * p.Lk + j) * p.ldk + h * HD + sub * 8;
-    const float* vp_ = V + ((long long)n * p.Lk + j) * p.ldv + h * HD + sub * 8;
+    const float* kp_ = K + (long long)n * p.bsk + (long long)j * p.ldk + h * HD + sub * 8;
+    const float* vp_ = V + (long long)n * p.bsv + (long long)j * p.ldv + h * HD + sub * 8;
 #pragma unroll
     for (int d = 0; d < 8; ++d) { k[d] = kp_[d] * p.scale; v[d] = vp_[d]; }
     if (p.mask_mode == 2) keymasked = p.kpm[(long long)n * p.Lk + j] != 0;
@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     ak[4] += ds * q1.x; ak[5] += ds * q1.y; ak[6] += ds * q1.z; ak[7] += ds * q1.w;
   }
   if (live) {
-    float* dk = dK + ((long long)n * p.Lk + j) * p.ldk + h * HD + sub * 8;
-    float* dv = dV + ((long long)n * p.Lk + j) * p.ldv + h * HD + sub * 8;
+    float* dk = dK + (long long)n * p.bsk + (long long)j * p.ldk + h * HD + sub * 8;
+    float* dv = dV + (long long)n * p.bsv + (long long)j * p.ldv + h * HD + sub * 8;
     *reinterpret_cast<float4*>(dk) = make_float4(ak[0], ak[1], ak[2], ak[3]);
     *reinterpret_cast<float4*>(dk + 4) = make_float4(ak[4], ak[5], ak[6], ak[7]);
     *reinterpret_cast<float4*>(dv) = make_float4(av[0], av[1], av[2], av[3]);
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   }
 }
 
-int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, int N, int H, int Lq, int Lk, float scale,
+int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, const long long* bs, int N, int H, int Lq, int Lk, float scale,
          int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
          uint32_t rng_stream) {
   CAPE_REQUIRE(Lq >= 1 && Lk >= 1 && Lq <= MAXL && Lk <= MAXL, "cape_attn: Lq=%d Lk=%d must be in 1..%d", Lq, Lk, MAXL);
@@ -252,7 +252,10 @@ int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, i
   CAPE_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "cape_attn: bad mask_mode %d", mask_mode);
   CAPE_REQUIRE(mask_mode != 2 || kpm, "cape_attn: key padding mask missing");
   CAPE_REQUIRE(dropout_p == 0.f || (rng_state && dropout_p < 1.f), "cape_attn: dropout needs rng_state");
-  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.N = N; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.bsq = bs[0]; p.bsk = bs[1]; p.bsv = bs[2]; p.bso = bs[3];
+  CAPE_REQUIRE((bs[0] % 4) == 0 && (bs[1] % 4) == 0 && (bs[2] % 4) == 0 && (bs[3] % 4) == 0, "cape_attn: batch strides must be multiples of 4");
+  p.N = N; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
   p.mask_mode = mask_mode; p.causal_offset = causal_offset; p.kpm = kpm;
   p.thresh = dropout_p > 0.f ? cape_drop_threshold(dropout_p) : 0u;
   p.inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
@@ -275,13 +278,15 @@ int raise_lds_limit() {
 }  // namespace
 
 extern "C" int cape_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, long long ldq,
-                             long long ldk, long long ldv, long long ldo, int N, int H, int Lq, int Lk, float scale,
+                             long long ldk, long long ldv, long long ldo, long long bsq, long long bsk, long long bsv,
+                             long long bso, int N, int H, int Lq, int Lk, float scale,
                              int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p,
                              const uint64_t* rng_state, uint32_t rng_stream, cape_stream_t stream) {
   CAPE_REQUIRE(Q && K && V && O && lse, "cape_attn_fwd: null pointer");
   if (N <= 0 || H <= 0) return 0;
   AttnP p;
-  if (fill(p, ldq, ldk, ldv, ldo, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
+  const long long bs[4] = {bsq, bsk, bsv, bso};
+  if (fill(p, ldq, ldk, ldv, ldo, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
   if (raise_lds_limit()) return 1;
   const size_t sh = (size_t)2 * Lk * HD * sizeof(float);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh, as_stream(stream), Q, K, V, O, lse, p);
@@ -291,13 +296,14 @@ extern "C" int cape_attn_fwd(const float* Q, const float* K, const float* V, flo
 
 extern "C" int cape_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* O,
                              const float* lse, float* dQ, float* dK, float* dV, long long ldq, long long ldk,
-                             long long ldv, long long ldo, int N, int H, int Lq, int Lk, float scale, int mask_mode,
-                             int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
+                             long long ldv, long long ldo, long long bsq, long long bsk, long long bsv, long long bso,
+                             int N, int H, int Lq, int Lk, float scale, int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
                              uint32_t rng_stream, cape_stream_t stream) {
   CAPE_REQUIRE(dO && Q && K && V && O && lse && dQ && dK && dV, "cape_attn_bwd: null pointer");
   if (N <= 0 || H <= 0) return 0;
   AttnP p;
-  if (fill(p, ldq, ldk, ldv, ldo, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
+  const long long bs[4] = {bsq, bsk, bsv, bso};
+  if (fill(p, ldq, ldk, ldv, ldo, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
   if (raise_lds_limit()) return 1;
   const size_t sh1 = (size_t)2 * Lk * HD * sizeof(float);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh1, as_stream(stream), dO, Q, K, V,

@@ -21,13 +21,14 @@ __global__ void next_tokens_kernel(const float* cls_logits, const float* reg, in
   if (unfinished[j]) {
     if (cls == 0 || (cls == 2 && i < min_len)) {
       const float x = fminf(reg[j * 2 + 0], 1.f), y = fminf(reg[j * 2 + 1], 1.f);
-      const float qx = x * (float)(nb - 1), qy = y * (float)(nb - 1);
+      // explicit rounding steps (no FMA contraction): the reference rounds x*43 before floor and subtract
+      const float qx = __fmul_rn(x, (float)(nb - 1)), qy = __fmul_rn(y, (float)(nb - 1));
       const float fx = floorf(qx), fy = floorf(qy), cx = ceilf(qx), cy = ceilf(qy);
       t11 = (int64_t)fx * nb + (int64_t)fy;
       t12 = (int64_t)fx * nb + (int64_t)cy;
       t21 = (int64_t)cx * nb + (int64_t)fy;
       t22 = (int64_t)cx * nb + (int64_t)cy;
-      dx = qx - fx; dy = qy - fy;
+      dx = __fsub_rn(qx, fx); dy = __fsub_rn(qy, fy);
     } else if (cls == 1) {
       t11 = t12 = t21 = t22 = sep_id;
     } else {
@@ -38,7 +39,7 @@ __global__ void next_tokens_kernel(const float* cls_logits, const float* reg, in
     t11 = t12 = t21 = t22 = pad_id;
   }
   tok[0 * N + j] = t11; tok[1 * N + j] = t12; tok[2 * N + j] = t21; tok[3 * N + j] = t22;
-  delta[0 * N + j] = dx; delta[1 * N + j] = 1.f - dx; delta[2 * N + j] = dy; delta[3 * N + j] = 1.f - dy;
+  delta[0 * N + j] = dx; delta[1 * N + j] = __fsub_rn(1.f, dx); delta[2 * N + j] = dy; delta[3 * N + j] = __fsub_rn(1.f, dy);
 }
 
 }  // namespace

@@ -1,0 +1,629 @@
+"""Autograd plumbing around the HIP kernels.
+
+Each `torch.autograd.Function` here is glue: forward and backward only *launch* kernels of
+libcape_hip.so (through `ops`) and keep the tensors backward needs.  No arithmetic of the hot path is
+done by torch ops in this file.
+"""
+import torch
+
+from . import ops
+
+
+class Runtime:
+    """Per-process runtime state shared by the Functions: dropout RNG state on device."""
+    rng = None
+
+    @classmethod
+    def get_rng(cls, device):
+        if cls.rng is None:
+            cls.rng = ops.RngState(0x5EED, device)
+        return cls.rng
+
+    @classmethod
+    def seed(cls, seed, device):
+        cls.rng = ops.RngState(int(seed), device)
+
+
+def _c(t):
+    return t if (t is None or t.is_contiguous()) else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear (+bias, +relu, +dropout, +residual) -- F.linear and its autograd
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu, dropout_p, rng_stream):
+        K = x.shape[-1]
+        N = weight.shape[0]
+        assert weight.shape[1] == K and weight.stride(1) == 1
+        x2 = _c(x).view(-1, K)
+        M = x2.shape[0]
+        res2 = _c(residual).view(-1, N) if residual is not None else None
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        rng = Runtime.get_rng(x.device) if dropout_p > 0 else None
+        ops.gemm(x2, weight, y, M, N, K, ldb=weight.stride(0), bias=bias, residual=res2, relu=relu, dropout_p=dropout_p,
+                 rng=rng, rng_stream=rng_stream)
+        ctx.save_for_backward(x2, weight, y if (relu or dropout_p > 0) else None)
+        ctx.meta = (relu, dropout_p, bias is not None, residual is not None, x.shape, M, N, K)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        relu, p, has_bias, has_res, xshape, M, N, K = ctx.meta
+        dy2 = _c(dy).view(M, N)
+        dpre = dy2
+        if relu or p > 0:
+            assert relu, "dropout epilogue is only used together with relu"
+            dpre = ops.relu_drop_bwd(dy2, y, 1.0 / (1.0 - p) if p > 0 else 1.0)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            ops.gemm(dpre, weight, dx, M, K, N, a_mode=0, b_mode=1, ldb=weight.stride(0))
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
+            ops.gemm(dpre, x2, dw, N, K, M, a_mode=1, b_mode=1, lda=N, ldb=K, accumulate=True,
+                     split_k=ops.pick_split_k(N, K, M))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+            ops.colsum(dpre, M, N, db)
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None, None
+
+
+def linear(x, weight, bias=None, residual=None, relu=False, dropout_p=0.0, rng_stream=0):
+    return LinearFn.apply(x, weight, bias, residual, relu, float(dropout_p), int(rng_stream))
+
+
+class LinearCat2Fn(torch.autograd.Function):
+    """[x W1^T + b1 | x W2^T + b2]  (sampling offsets | attention logits of MSDeformAttn)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        K = x.shape[-1]
+        N1, N2 = w1.shape[0], w2.shape[0]
+        x2 = _c(x).view(-1, K)
+        M = x2.shape[0]
+        y = torch.empty(M, N1 + N2, dtype=torch.float32, device=x.device)
+        ops.gemm(x2, w1, y, M, N1, K, bias=b1, ldc=N1 + N2)
+        ops.gemm(x2, w2, y[:, N1:], M, N2, K, bias=b2, ldc=N1 + N2)
+        ctx.save_for_backward(x2, w1, w2)
+        ctx.meta = (x.shape, M, N1, N2, K)
+        return y.view(*x.shape[:-1], N1 + N2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2 = ctx.saved_tensors
+        xshape, M, N1, N2, K = ctx.meta
+        NT = N1 + N2
+        dy2 = _c(dy).view(M, NT)
+        dev = dy.device
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            ops.gemm(dy2, w1, dx, M, K, N1, a_mode=0, b_mode=1, lda=NT)
+            ops.gemm(dy2[:, N1:], w2, dx, M, K, N2, a_mode=0, b_mode=1, lda=NT, accumulate=True)
+            dx = dx.view(xshape)
+        dw1 = torch.zeros(N1, K, dtype=torch.float32, device=dev)
+        dw2 = torch.zeros(N2, K, dtype=torch.float32, device=dev)
+        ops.gemm(dy2, x2, dw1, N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M))
+        ops.gemm(dy2[:, N1:], x2, dw2, N2, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True,
+                 split_k=ops.pick_split_k(N2, K, M))
+        db = torch.zeros(NT, dtype=torch.float32, device=dev)
+        ops.colsum(dy2, M, NT, db)
+        return dx, dw1, db[:N1], dw2, db[N1:]
+
+
+def linear_cat2(x, w1, b1, w2, b2):
+    return LinearCat2Fn.apply(x, w1, b1, w2, b2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Convolution (NHWC, channels_last weights) + folded FrozenBN / bias + ReLU + residual
+# ------------------------------------------------------------------------------------------------
+def _w_phys(weight):
+    """(O, C, KH, KW) channels_last parameter -> its physical (O, KH, KW, C) contiguous view."""
+    wp = weight.permute(0, 2, 3, 1)
+    assert wp.is_contiguous(), "conv weights must be stored channels_last"
+    return wp
+
+
+class ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu):
+        # x (N, H, W, C) contiguous NHWC
+        x = _c(x)
+        N, H, W, C = x.shape
+        O, C2, KH, KW = weight.shape
+        assert C2 == C
+        wp = _w_phys(weight)
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        M, K = N * OH * OW, KH * KW * C
+        y = torch.empty(N, OH, OW, O, dtype=torch.float32, device=x.device)
+        res = _c(residual) if residual is not None else None
+        geom = (N, H, W, C, KH, KW, stride, pad, OH, OW, O)
+        dense = KH == 1 and KW == 1 and stride == 1 and pad == 0
+        if dense:
+            ops.gemm(x, wp, y, M, O, K, scale=scale, bias=shift, residual=res, relu=relu)
+        else:
+            ops.gemm(x, wp, y, M, O, K, a_mode=2, b_mode=0, conv=geom, scale=scale, bias=shift, residual=res, relu=relu)
+        ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.meta = (geom, dense, relu, shift is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, scale, y = ctx.saved_tensors
+        geom, dense, relu, has_shift, has_res = ctx.meta
+        N, H, W, C, KH, KW, stride, pad, OH, OW, O = geom
+        dy = _c(dy)
+        M, K = N * OH * OW, KH * KW * C
+        want_res = has_res and ctx.needs_input_grad[4]
+        if relu or scale is not None or want_res:
+            dpre, dres = ops.bn_relu_bwd(dy, y if relu else dy, scale, relu, want_res) if scale is not None else \
+                _relu_bwd_noscale(dy, y, relu, want_res)
+        else:
+            dpre, dres = dy, None
+        wp = _w_phys(weight)
+        dx = dw = dshift = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(N, H, W, C, dtype=torch.float32, device=dy.device)
+            if dense:
+                ops.gemm(dpre, wp, dx, M, C, O, a_mode=0, b_mode=1)
+            else:
+                ops.gemm(dpre, wp, dx, N * H * W, C, KH * KW * O, a_mode=3, b_mode=2, conv=geom)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(O, KH, KW, C, dtype=torch.float32, device=dy.device)
+            if dense:
+                ops.gemm(dpre, x, dwp, O, C, M, a_mode=1, b_mode=1, lda=O, ldb=C, accumulate=True,
+                         split_k=ops.pick_split_k(O, C, M))
+            else:
+                ops.gemm(dpre, x, dwp, O, K, M, a_mode=1, b_mode=3, lda=O, conv=geom, accumulate=True,
+                         split_k=ops.pick_split_k(O, K, M))
+            dw = dwp.permute(0, 3, 1, 2)
+        if has_shift and ctx.needs_input_grad[3]:
+            dshift = torch.zeros(O, dtype=torch.float32, device=dy.device)
+            ops.colsum(dpre if scale is None else (dres if dres is not None else _mask_only(dy, y, relu)), M, O, dshift)
+        return dx, dw, None, dshift, dres, None, None, None
+
+
+def _relu_bwd_noscale(dy, y, relu, want_res):
+    if not relu:
+        return dy, (dy if want_res else None)
+    d = ops.relu_drop_bwd(dy, y, 1.0)
+    return d, (d if want_res else None)
+
+
+def _mask_only(dy, y, relu):
+    return ops.relu_drop_bwd(dy, y, 1.0) if relu else dy
+
+
+def conv_bn_act(x, weight, scale, shift, stride=1, pad=0, relu=False, residual=None):
+    return ConvFn.apply(x, weight, scale, shift, residual, int(stride), int(pad), bool(relu))
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm(x + dropout(y)) [+ pos]
+# ------------------------------------------------------------------------------------------------
+class AddLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, pos, dropout_p, rng_stream):
+        x, y, pos = _c(x), _c(y), _c(pos)
+        rng = Runtime.get_rng(x.device) if dropout_p > 0 else None
+        out, mean, rstd, out_pos = ops.add_layernorm_fwd(x, y, gamma, beta, pos=pos, dropout_p=dropout_p, rng=rng,
+                                                         rng_stream=rng_stream)
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.meta = (dropout_p, rng_stream, pos is not None)
+        if pos is None:
+            return out
+        return out, out_pos
+
+    @staticmethod
+    def backward(ctx, d_out, d_out_pos=None):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        p, stream, has_pos = ctx.meta
+        if d_out is None:
+            d_out, d_out_pos = d_out_pos, None
+            d_pos_only = d_out
+        d_out, d_out_pos = _c(d_out), _c(d_out_pos)
+        C = x.shape[-1]
+        dg = torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        rng = Runtime.get_rng(x.device) if p > 0 else None
+        dx, dy = ops.add_layernorm_bwd(d_out, d_out_pos, x, y, gamma, mean, rstd, dg, db, dropout_p=p, rng=rng,
+                                       rng_stream=stream)
+        dpos = None
+        if has_pos and ctx.needs_input_grad[4]:
+            dpos = d_out_pos if d_out_pos is not None else None
+        return dx, (dy if y is not None else None), dg, db, dpos, None, None
+
+
+def add_layernorm(x, y, gamma, beta, pos=None, dropout_p=0.0, rng_stream=0):
+    return AddLayerNormFn.apply(x, y, gamma, beta, pos, float(dropout_p), int(rng_stream))
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(_c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# input_proj GroupNorm of all levels, written straight into the flattened token buffer
+# ------------------------------------------------------------------------------------------------
+class LevelGroupNormFn(torch.autograd.Function):
+    """xs: L tensors (N, h_l, w_l, C) NHWC; returns src_flatten (N, S, C)."""
+
+    @staticmethod
+    def forward(ctx, geo, *args):
+        L = geo.L
+        xs, gammas, betas = args[:L], args[L:2 * L], args[2 * L:3 * L]
+        N, C = xs[0].shape[0], xs[0].shape[-1]
+        out = torch.empty(N, geo.S, C, dtype=torch.float32, device=xs[0].device)
+        stats = []
+        xs = [_c(x) for x in xs]
+        for l, x in enumerate(xs):
+            h, w = geo.shapes[l]
+            assert x.shape[1] == h and x.shape[2] == w
+            stats.append(ops.groupnorm_fwd(x, gammas[l], betas[l], out[:, geo.starts[l]:], geo.S * C, N, h * w, C))
+        ctx.geo = geo
+        ctx.save_for_backward(*xs, *gammas, *[s for st in stats for s in st])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        geo = ctx.geo
+        L = geo.L
+        sv = ctx.saved_tensors
+        xs, gammas, st = sv[:L], sv[L:2 * L], sv[2 * L:]
+        d_out = _c(d_out)
+        N, S, C = d_out.shape
+        dxs, dgs, dbs = [], [], []
+        for l in range(L):
+            h, w = geo.shapes[l]
+            dg = torch.zeros(C, dtype=torch.float32, device=d_out.device)
+            db = torch.zeros(C, dtype=torch.float32, device=d_out.device)
+            dx = ops.groupnorm_bwd(d_out[:, geo.starts[l]:], S * C, xs[l], gammas[l], st[2 * l], st[2 * l + 1], dg, db, N,
+                                   h * w, C)
+            dxs.append(dx); dgs.append(dg); dbs.append(db)
+        return (None, *dxs, *dgs, *dbs)
+
+
+def level_groupnorm(geo, xs, gammas, betas):
+    return LevelGroupNormFn.apply(geo, *xs, *gammas, *betas)
+
+
+class LevelPosFn(torch.autograd.Function):
+    """Image sine position embedding + level_embed, flattened (N, S, C)."""
+
+    @staticmethod
+    def forward(ctx, geo, level_embed, *masks_u8):
+        N = masks_u8[0].shape[0]
+        C = level_embed.shape[1]
+        out = torch.empty(N, geo.S, C, dtype=torch.float32, device=level_embed.device)
+        for l, m in enumerate(masks_u8):
+            h, w = geo.shapes[l]
+            ops.pos_sine_level(_c(m), level_embed[l], out[:, geo.starts[l]:], geo.S * C, N, h, w, C)
+        ctx.geo = geo
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, d_pos):
+        geo, N = ctx.geo, ctx.N
+        d_pos = _c(d_pos)
+        C = d_pos.shape[-1]
+        d_le = torch.zeros(geo.L, C, dtype=torch.float32, device=d_pos.device)
+        for l in range(geo.L):
+            h, w = geo.shapes[l]
+            for n in range(N):
+                ops.colsum(d_pos[n, geo.starts[l]:], h * w, C, d_le[l])
+        return (None, d_le) + (None,) * geo.L
+
+
+def level_pos(geo, level_embed, masks_u8):
+    return LevelPosFn.apply(geo, level_embed, *masks_u8)
+
+
+# ------------------------------------------------------------------------------------------------
+# MSDA core
+# ------------------------------------------------------------------------------------------------
+class MSDAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, offw, ref, geo, P):
+        value, offw, ref = _c(value), _c(offw), _c(ref)
+        N, Lq = offw.shape[0], offw.shape[1]
+        out = ops.msda_fwd(value, offw, ref, geo, N, Lq, P)
+        ctx.save_for_backward(value, offw, ref)
+        ctx.meta = (geo, N, Lq, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        value, offw, ref = ctx.saved_tensors
+        geo, N, Lq, P = ctx.meta
+        dv, do, dr = ops.msda_bwd(_c(d_out), value, offw, ref, geo, N, Lq, P, need_ref_grad=ctx.needs_input_grad[2])
+        return dv, do, dr, None, None
+
+
+def msda(value, offw, ref, geo, P=4):
+    return MSDAFn.apply(value, offw, ref, geo, P)
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.MultiheadAttention (in_proj + core + out_proj) as one node
+# ------------------------------------------------------------------------------------------------
+class MHAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_in, k_in, v_in, in_w, in_b, out_w, out_b, nheads, mask_mode, kpm_u8, dropout_p, rng_stream):
+        q_in, k_in, v_in = _c(q_in), _c(k_in), _c(v_in)
+        N, Lq, C = q_in.shape
+        Lk = k_in.shape[1]
+        dev = q_in.device
+        q = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+        k = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+        v = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+        ops.gemm(q_in.view(-1, C), in_w, q, N * Lq, C, C, bias=in_b)
+        ops.gemm(k_in.view(-1, C), in_w[C:], k, N * Lk, C, C, bias=in_b[C:])
+        ops.gemm(v_in.view(-1, C), in_w[2 * C:], v, N * Lk, C, C, bias=in_b[2 * C:])
+        scale = (C // nheads) ** -0.5
+        rng = Runtime.get_rng(dev) if dropout_p > 0 else None
+        O, lse = ops.attn_fwd(q, k, v, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm_u8, dropout_p=dropout_p,
+                              rng=rng, rng_stream=rng_stream)
+        out = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+        ops.gemm(O.view(-1, C), out_w, out, N * Lq, C, C, bias=out_b)
+        ctx.save_for_backward(q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm_u8)
+        ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm = ctx.saved_tensors
+        nheads, mask_mode, p, stream, scale, kv_same, qk_same = ctx.meta
+        N, Lq, C = q_in.shape
+        Lk = k_in.shape[1]
+        dev = d_out.device
+        d_out2 = _c(d_out).view(-1, C)
+        Mq, Mk = N * Lq, N * Lk
+        dO = torch.empty(Mq, C, dtype=torch.float32, device=dev)
+        ops.gemm(d_out2, out_w, dO, Mq, C, C, a_mode=0, b_mode=1)
+        d_out_w = torch.zeros(C, C, dtype=torch.float32, device=dev)
+        ops.gemm(d_out2, O.view(-1, C), d_out_w, C, C, Mq, a_mode=1, b_mode=1, accumulate=True,
+                 split_k=ops.pick_split_k(C, C, Mq))
+        d_out_b = torch.zeros(C, dtype=torch.float32, device=dev)
+        ops.colsum(d_out2, Mq, C, d_out_b)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        rng = Runtime.get_rng(dev) if p > 0 else None
+        ops.attn_bwd(dO.view(N, Lq, C), q, k, v, O, lse, dq, dk, dv, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm,
+                     dropout_p=p, rng=rng, rng_stream=stream)
+        d_in_w = torch.zeros(3 * C, C, dtype=torch.float32, device=dev)
+        d_in_b = torch.zeros(3 * C, dtype=torch.float32, device=dev)
+        for i, (g, src, M) in enumerate(((dq, q_in, Mq), (dk, k_in, Mk), (dv, v_in, Mk))):
+            ops.gemm(g.view(-1, C), src.view(-1, C), d_in_w[i * C:], C, C, M, a_mode=1, b_mode=1, accumulate=True,
+                     split_k=ops.pick_split_k(C, C, M))
+            ops.colsum(g.view(-1, C), M, C, d_in_b[i * C:])
+        dq_in = dk_in = dv_in = None
+        if ctx.needs_input_grad[0]:
+            dq_in = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+            ops.gemm(dq.view(-1, C), in_w, dq_in, Mq, C, C, a_mode=0, b_mode=1)
+        if ctx.needs_input_grad[1]:
+            dk_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+            ops.gemm(dk.view(-1, C), in_w[C:], dk_in, Mk, C, C, a_mode=0, b_mode=1)
+        if ctx.needs_input_grad[2]:
+            dv_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+            ops.gemm(dv.view(-1, C), in_w[2 * C:], dv_in, Mk, C, C, a_mode=0, b_mode=1)
+        return dq_in, dk_in, dv_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None, None
+
+
+def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, nheads=8, mask_mode=0, kpm_u8=None, dropout_p=0.0, rng_stream=0):
+    return MHAFn.apply(q_in, k_in, v_in, in_w, in_b, out_w, out_b, nheads, mask_mode, kpm_u8, float(dropout_p), int(rng_stream))
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder embedding / reference-point ops
+# ------------------------------------------------------------------------------------------------
+class TokenEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, pad_idx, s11, s21, s12, s22, dx1, dx2, dy1, dy2):
+        shape = s11.shape
+        seqs = [_c(s).view(-1) for s in (s11, s21, s12, s22)]
+        deltas = [_c(d).view(-1) for d in (dx1, dx2, dy1, dy2)]
+        out = ops.token_embed_fwd(table, seqs, deltas)
+        ctx.save_for_backward(*seqs, *deltas)
+        ctx.meta = (table.shape, pad_idx)
+        return out.view(*shape, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, d_out):
+        sv = ctx.saved_tensors
+        tshape, pad_idx = ctx.meta
+        d_table = torch.zeros(tshape, dtype=torch.float32, device=d_out.device)
+        ops.token_embed_bwd(_c(d_out).view(-1, tshape[1]), sv[:4], sv[4:], d_table, pad_idx if pad_idx is not None else -1)
+        return (d_table,) + (None,) * 9
+
+
+def token_embed(table, pad_idx, s11, s21, s12, s22, dx1, dx2, dy1, dy2):
+    return TokenEmbedFn.apply(table, pad_idx, s11, s21, s12, s22, dx1, dx2, dy1, dy2)
+
+
+class QuerySineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref):
+        ref = _c(ref)
+        ctx.save_for_backward(ref)
+        return ops.query_sine_fwd(ref).view(*ref.shape[:-1], 256)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (ref,) = ctx.saved_tensors
+        return ops.query_sine_bwd(_c(d_out).view(-1, 256), ref).view_as(ref)
+
+
+def query_sine(ref):
+    return QuerySineFn.apply(ref)
+
+
+class RefineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, delta, ref):
+        delta, ref = _c(delta), _c(ref)
+        out = ops.refine_fwd(delta, ref)
+        ctx.save_for_backward(out, ref)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_new):
+        out, ref = ctx.saved_tensors
+        d_delta, d_ref = ops.refine_bwd(_c(d_new), out, ref)
+        return d_delta, d_ref
+
+
+def refine(delta, ref):
+    return RefineFn.apply(delta, ref)
+
+
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.sigmoid_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.sigmoid_bwd(_c(dy), y)
+
+
+def sigmoid(x):
+    return SigmoidFn.apply(x)
+
+
+class RefScaleFn(torch.autograd.Function):
+    """ref (N, Lq, 2) * valid_ratios (N, L, 2) -> (N, Lq, L, 2)"""
+
+    @staticmethod
+    def forward(ctx, ref, valid_ratios):
+        ref, vr = _c(ref), _c(valid_ratios)
+        N, Lq, _ = ref.shape
+        L = vr.shape[1]
+        ctx.save_for_backward(vr)
+        ctx.meta = (N, Lq, L)
+        return ops.ref_scale_fwd(ref, vr, Lq, L).view(N, Lq, L, 2)
+
+    @staticmethod
+    def backward(ctx, d):
+        (vr,) = ctx.saved_tensors
+        N, Lq, L = ctx.meta
+        return ops.ref_scale_bwd(_c(d), vr, Lq, L).view(N, Lq, 2), None
+
+
+def ref_scale(ref, valid_ratios):
+    return RefScaleFn.apply(ref, valid_ratios)
+
+
+# ------------------------------------------------------------------------------------------------
+# support encoder pieces
+# ------------------------------------------------------------------------------------------------
+class SupportEmbedFn(torch.autograd.Function):
+    """coords (N,P,2) -> h = relu(Linear_2->C(coords)) (N,P,C), pe = sine2d + pe1d (N,P,C; no gradient)."""
+
+    @staticmethod
+    def forward(ctx, coords, W0, b0, pe1d):
+        coords = _c(coords)
+        N, P, _ = coords.shape
+        C = W0.shape[0]
+        h, pe = ops.support_embed_fwd(coords, W0, b0, pe1d, N, P, C)
+        ctx.save_for_backward(h, coords)
+        ctx.meta = (N, P, C)
+        ctx.mark_non_differentiable(pe)
+        return h.view(N, P, C), pe.view(N, P, C)
+
+    @staticmethod
+    def backward(ctx, d_h, _d_pe):
+        h, coords = ctx.saved_tensors
+        N, P, C = ctx.meta
+        dW = torch.zeros(C, 2, dtype=torch.float32, device=h.device)
+        db = torch.zeros(C, dtype=torch.float32, device=h.device)
+        ops.support_embed_bwd(_c(d_h).view(-1, C), h, coords, dW, db, N, P, C)
+        return None, dW, db, None
+
+
+def support_embed(coords, W0, b0, pe1d):
+    return SupportEmbedFn.apply(coords, W0, b0, pe1d)
+
+
+class GCNAggFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, adj):
+        y = _c(y)
+        N, P, C2 = y.shape
+        out = ops.gcn_aggregate_fwd(y, adj, N, P, C2 // 2)
+        ctx.save_for_backward(out, adj)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, adj = ctx.saved_tensors
+        N, P, C = out.shape
+        return ops.gcn_aggregate_bwd(_c(d_out), out, adj, N, P, C), None
+
+
+def gcn_aggregate(y, adj):
+    return GCNAggFn.apply(y, adj)
+
+
+class ZeroRowsFn(torch.autograd.Function):
+    """x[rowmask] = 0 (the all-masked guard of the support encoder); gradient is masked the same way."""
+
+    @staticmethod
+    def forward(ctx, x, rowmask_u8):
+        x = _c(x).clone()
+        ops.zero_rows(x, rowmask_u8)
+        ctx.save_for_backward(rowmask_u8)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (rm,) = ctx.saved_tensors
+        g = _c(g).clone()
+        ops.zero_rows(g, rm)
+        return g, None
+
+
+def zero_rows(x, rowmask_u8):
+    return ZeroRowsFn.apply(x, rowmask_u8)
+
+
+# ------------------------------------------------------------------------------------------------
+# criterion
+# ------------------------------------------------------------------------------------------------
+class LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, coords, labels, vis_u8, target, class_w, w_ce, w_l1):
+        losses, total, dl, dc = ops.loss_fwd_bwd(_c(logits), _c(coords), _c(labels).view(-1), _c(vis_u8).view(-1),
+                                                 _c(target).view(-1, 2), class_w, w_ce, w_l1, 1.0)
+        ctx.save_for_backward(dl, dc)
+        ctx.mark_non_differentiable(losses)
+        return total.view(()), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        dl, dc = ctx.saved_tensors
+        # scaling by the incoming scalar gradient is glue (1/accumulation_steps)
+        return dl * g_total, dc * g_total, None, None, None, None, None, None
+
+
+def cape_loss(logits, coords, labels, vis_u8, target, class_w, w_ce, w_l1):
+    return LossFn.apply(logits, coords, labels, vis_u8, target, class_w, float(w_ce), float(w_l1))

@@ -22,6 +22,11 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _avail(t):
+    """Elements addressable from the tensor's first element to the end of its storage."""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
 def _chk(t, name, dtype=_F32, contiguous=True):
     if t is None:
         return
@@ -90,17 +95,17 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.rng_stream = rng_stream
     # host-side extent checks (dense modes)
     if a_mode == 0 and M > 0:
-        assert A.numel() >= (M - 1) * d.lda + K, "gemm: A too small"
+        assert _avail(A) >= (M - 1) * d.lda + K, "gemm: A too small"
     if a_mode == 1 and K > 0:
-        assert A.numel() >= (K - 1) * d.lda + M, "gemm: A^T too small"
+        assert _avail(A) >= (K - 1) * d.lda + M, "gemm: A^T too small"
     if b_mode == 0 and N > 0:
-        assert B.numel() >= (N - 1) * d.ldb + K, "gemm: B too small"
+        assert _avail(B) >= (N - 1) * d.ldb + K, "gemm: B too small"
     if b_mode == 1 and K > 0:
-        assert B.numel() >= (K - 1) * d.ldb + N, "gemm: B too small"
+        assert _avail(B) >= (K - 1) * d.ldb + N, "gemm: B too small"
     if M > 0:
-        assert C.numel() >= (M - 1) * d.ldc + N, "gemm: C too small"
+        assert _avail(C) >= (M - 1) * d.ldc + N, "gemm: C too small"
     if residual is not None:
-        assert residual.numel() >= (M - 1) * d.ldr + N, "gemm: residual too small"
+        assert _avail(residual) >= (M - 1) * d.ldr + N, "gemm: residual too small"
     if bias is not None:
         assert bias.numel() >= N
     if scale is not None:
@@ -112,8 +117,8 @@ def colsum(X, M, N, out, ldx=None, accumulate=True):
     _chk(X, "colsum.X", contiguous=False)
     _chk(out, "colsum.out")
     ldx = N if ldx is None else ldx
-    assert M == 0 or X.numel() >= (M - 1) * ldx + N
-    assert out.numel() >= N
+    assert M == 0 or _avail(X) >= (M - 1) * ldx + N
+    assert _avail(out) >= N
     lib.call("cape_colsum_f32", _p(X), ldx, M, N, _p(out), int(accumulate), _stream())
 
 
@@ -222,15 +227,17 @@ def _ld(t):
 
 def attn_fwd(Q, K, V, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0, rng=None, rng_stream=0):
     """Q (N,Lq,*) K,V (N,Lk,*) as (possibly strided) views whose last dim holds H*32 head channels."""
-    for t, n in ((Q, "Q"), (K, "K"), (V, "V")):
+    for t, n, L_ in ((Q, "Q", Lq), (K, "K", Lk), (V, "V", Lk)):
         _chk(t, "attn." + n, contiguous=False)
-        assert t.stride(0) == t.shape[1] * t.stride(1), "attn: batch stride must be L*ld"
+        assert t.dim() == 3 and t.shape[0] == N and t.shape[1] >= L_ and t.shape[2] == H * 32
+        assert _avail(t) >= (N - 1) * t.stride(0) + (L_ - 1) * t.stride(1) + H * 32
     if kpm is not None:
         _chk(kpm, "attn.kpm", dtype=torch.uint8)
         assert kpm.numel() == N * Lk
     O = torch.empty(N, Lq, H * 32, dtype=_F32, device=Q.device)
     lse = torch.empty(N, H, Lq, dtype=_F32, device=Q.device)
-    lib.call("cape_attn_fwd", _p(Q), _p(K), _p(V), _p(O), _p(lse), _ld(Q), _ld(K), _ld(V), H * 32, N, H, Lq, Lk,
+    lib.call("cape_attn_fwd", _p(Q), _p(K), _p(V), _p(O), _p(lse), _ld(Q), _ld(K), _ld(V), H * 32,
+             Q.stride(0), K.stride(0), V.stride(0), Lq * H * 32, N, H, Lq, Lk,
              float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
              rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
     return O, lse
@@ -242,8 +249,10 @@ def attn_bwd(dO, Q, K, V, O, lse, dQ, dK, dV, N, H, Lq, Lk, scale, mask_mode=0, 
     for t in (dQ, dK, dV):
         _chk(t, "attn_bwd.grad", contiguous=False)
     assert _ld(dQ) == _ld(Q) and _ld(dK) == _ld(K) and _ld(dV) == _ld(V)
+    assert dQ.stride(0) == Q.stride(0) and dK.stride(0) == K.stride(0) and dV.stride(0) == V.stride(0)
+    assert O.is_contiguous() and dO.shape == O.shape
     lib.call("cape_attn_bwd", _p(dO), _p(Q), _p(K), _p(V), _p(O), _p(lse), _p(dQ), _p(dK), _p(dV), _ld(Q), _ld(K), _ld(V),
-             H * 32, N, H, Lq, Lk, float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
+             H * 32, Q.stride(0), K.stride(0), V.stride(0), Lq * H * 32, N, H, Lq, Lk, float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
              rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
 
 

@@ -1,0 +1,42 @@
+"""Skeleton graph utilities (reference `models/graph_utils.py:15-186`) on MI355X kernels:
+`adj_from_skeleton` builds the dual-channel normalised adjacency on device from a flattened edge list,
+`GCNLayer` = 1x1 Conv1d (a GEMM) + adjacency aggregation + ReLU."""
+import torch
+import torch.nn as nn
+
+from ..hip import functional as HF
+from ..hip import ops
+
+
+def adj_from_skeleton(num_pts, skeleton, mask, device="cuda"):
+    """skeleton: list (len bs) of [[i, j], ...] 0-indexed; mask (bs, num_pts) bool, True = ignore.
+    Returns (bs, 2, num_pts, num_pts): [diag(~mask), row-normalised symmetric adjacency]."""
+    bs = len(skeleton)
+    flat, start = [], [0]
+    for edges in skeleton:
+        for e in edges:
+            flat.append((int(e[0]), int(e[1])))
+        start.append(len(flat))
+    dev = mask.device if isinstance(mask, torch.Tensor) else torch.device(device)
+    edges_t = torch.tensor(flat if flat else [(0, 0)], dtype=torch.int32, device=dev).contiguous()
+    start_t = torch.tensor(start, dtype=torch.int32, device=dev)
+    return ops.adjacency(edges_t, start_t, mask.to(torch.uint8).contiguous(), bs, num_pts)
+
+
+class GCNLayer(nn.Module):
+    def __init__(self, in_features, out_features, kernel_size=2, use_bias=True, activation=nn.ReLU(inplace=True),
+                 batch_first=True):
+        super().__init__()
+        if kernel_size != 2 or not isinstance(activation, nn.ReLU) or in_features != out_features:
+            raise ValueError("MI355X GCN kernel: kernel_size=2 (self + neighbours), ReLU, square features")
+        self.conv = nn.Conv1d(in_features, out_features * kernel_size, kernel_size=1, bias=use_bias)
+        self.kernel_size, self.activation, self.batch_first = kernel_size, activation, batch_first
+
+    def forward(self, x, adj):
+        assert adj.size(1) == self.kernel_size, \
+            f"Adjacency channel dim {adj.size(1)} must match kernel_size {self.kernel_size}"
+        if not self.batch_first:
+            x = x.transpose(0, 1).contiguous()
+        y = HF.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)      # (bs, P, 2*C): channel = k*C + c
+        out = HF.gcn_aggregate(y, adj.contiguous())
+        return out if self.batch_first else out.transpose(0, 1).contiguous()

@@ -1,0 +1,261 @@
+"""RoomFormerV2 base model of CAPE on MI355X kernels: backbone -> input_proj (1x1 / 3x3-s2 conv as
+implicit GEMM + GroupNorm written straight into the flattened token buffer) -> deformable
+transformer; teacher-forced `forward` and KV-cached autoregressive `forward_inference` whose token
+bookkeeping runs on the device.  Interface and parameter names follow the reference
+(`models/roomformer_v2.py:149-693, :956-1049`)."""
+import copy
+import math
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from ..hip import functional as HF
+from ..hip import ops
+from ..util.misc import NestedTensor, nested_tensor_from_tensor_list
+from .backbone import Conv2dCL, build_backbone
+from .deformable_transformer_v2 import build_deforamble_transformer
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class MLP(nn.Module):
+    """Very simple multi-layer perceptron (roomformer_v2.py:956-968); applied through HIP GEMMs."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = HF.linear(x, layer.weight, layer.bias, relu=(i < self.num_layers - 1))
+        return x
+
+
+class RoomFormerV2(nn.Module):
+    def __init__(self, backbone, transformer, num_classes, num_queries, num_polys, num_feature_levels, aux_loss=True,
+                 with_poly_refine=False, masked_attn=False, semantic_classes=-1, seq_len=1024, tokenizer=None,
+                 use_anchor=False, patch_size=1, freeze_anchor=False, inject_cls_embed=False, cape_mode=False):
+        super().__init__()
+        assert num_queries % num_polys == 0
+        if cape_mode:
+            raise ValueError("cape_mode=True (RoomFormerV2-internal SupportPoseEncoder) is not on the CAPE path; "
+                             "models.build_model always passes cape_mode=False")
+        if not with_poly_refine or use_anchor or inject_cls_embed or num_feature_levels != 4:
+            raise ValueError("CAPE path: with_poly_refine=True, use_anchor=False, inject_cls_embed=False, 4 feature levels")
+        self.num_queries, self.num_polys = num_queries, num_polys
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.num_classes = num_classes
+        self.cape_mode = cape_mode
+        self.class_embed = nn.Linear(hidden_dim, num_classes)
+        self.coords_embed = MLP(hidden_dim, hidden_dim, 2, 3)
+        self.num_feature_levels = num_feature_levels
+        self.tokenizer = tokenizer
+        self.seq_len = seq_len
+        self.patch_size = patch_size
+        self.inject_cls_embed = inject_cls_embed
+        num_backbone_outs = len(backbone.strides)
+        proj = []
+        in_channels = None
+        for i in range(num_backbone_outs):
+            in_channels = backbone.num_channels[i]
+            proj.append(nn.Sequential(Conv2dCL(in_channels, hidden_dim, patch_size, stride=patch_size, padding=0, bias=True),
+                                      nn.GroupNorm(32, hidden_dim)))
+        for _ in range(num_feature_levels - num_backbone_outs):
+            if patch_size == 1:
+                proj.append(nn.Sequential(Conv2dCL(in_channels, hidden_dim, 3, stride=2, padding=1, bias=True),
+                                          nn.GroupNorm(32, hidden_dim)))
+            else:
+                proj.append(nn.Sequential(Conv2dCL(in_channels, hidden_dim, 2 * patch_size, stride=2 * patch_size, padding=0,
+                                                   bias=True), nn.GroupNorm(32, hidden_dim)))
+            in_channels = hidden_dim
+        self.input_proj = nn.ModuleList(proj)
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.with_poly_refine = with_poly_refine
+
+        prior_prob = 0.01
+        bias_value = -math.log((1 - prior_prob) / prior_prob)
+        self.class_embed.bias.data = torch.ones(num_classes) * bias_value
+        nn.init.constant_(self.coords_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.coords_embed.layers[-1].bias.data, 0)
+        for p in self.input_proj:
+            w = torch.empty_like(p[0].weight, memory_format=torch.contiguous_format)
+            nn.init.xavier_uniform_(w, gain=1)
+            with torch.no_grad():
+                p[0].weight.copy_(w)
+            nn.init.constant_(p[0].bias, 0)
+        num_pred = transformer.decoder.num_layers
+        self.class_embed = _get_clones(self.class_embed, num_pred)
+        self.coords_embed = _get_clones(self.coords_embed, num_pred)
+        nn.init.constant_(self.coords_embed[0].layers[-1].bias.data[2:], -2.0)
+        self.query_embed = nn.Embedding(seq_len, 2)
+        self.query_embed.weight.requires_grad = not freeze_anchor
+        self.transformer.decoder.coords_embed = self.coords_embed
+        self.transformer.decoder.class_embed = self.class_embed
+        self.room_class_embed = None
+        if semantic_classes > 0:
+            self.room_class_embed = nn.Linear(hidden_dim, semantic_classes)
+        self.register_buffer("attention_mask", self._create_causal_attention_mask(seq_len))
+
+    @staticmethod
+    def _create_causal_attention_mask(seq_len):
+        mask = torch.triu(torch.ones(seq_len, seq_len), diagonal=1)
+        return mask.masked_fill(mask == 1, float("-inf")).masked_fill(mask == 0, 0.0)
+
+    # ---- image side shared by forward / forward_inference ----------------------------------------
+    def _encode_images(self, samples):
+        has_padding = True
+        if not isinstance(samples, NestedTensor):
+            has_padding = not (isinstance(samples, torch.Tensor) and samples.ndim == 4)
+            samples = nested_tensor_from_tensor_list(samples)
+        elif samples.mask is not None:
+            has_padding = bool(samples.mask.any())
+        features = self.backbone(samples)
+        srcs, masks = [], []
+        last = None
+        for l, feat in enumerate(features):
+            x, mask = feat.decompose()
+            conv = self.input_proj[l][0]
+            src = HF.conv_bn_act(x, conv.weight, None, conv.bias, conv.stride, conv.padding, relu=False)
+            if self.patch_size != 1:
+                mask = _nearest_mask(mask, src.shape[1], src.shape[2])
+            srcs.append(src); masks.append(mask)
+            last = x
+        for l in range(len(features), self.num_feature_levels):
+            conv = self.input_proj[l][0]
+            inp = last if l == len(features) else srcs[-1]
+            src = HF.conv_bn_act(inp, conv.weight, None, conv.bias, conv.stride, conv.padding, relu=False)
+            masks.append(_nearest_mask(samples.mask, src.shape[1], src.shape[2]))
+            srcs.append(src)
+        gammas = [p[1].weight for p in self.input_proj]
+        betas = [p[1].bias for p in self.input_proj]
+        return self.transformer.encode(srcs, (gammas, betas), masks, has_padding)
+
+    def forward(self, samples, seq_kwargs=None, support_graphs=None, support_mask=None):
+        """Teacher-forced pass.  Returns {'pred_logits', 'pred_coords', 'pred_room_logits', 'aux_outputs'}."""
+        enc = self._encode_images(samples)
+        hs, init_reference, inter_references, inter_classes = self.transformer(enc, self.query_embed.weight, seq_kwargs)
+        out = {"pred_logits": inter_classes[-1], "pred_coords": inter_references[-1]}
+        if self.room_class_embed is not None:
+            out["pred_room_logits"] = HF.linear(hs[-1], self.room_class_embed.weight, self.room_class_embed.bias)
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_coords": b}
+                                  for a, b in zip(inter_classes[:-1], inter_references[:-1])]
+        # kept for the criterion: stacked per-layer outputs avoid re-stacking in the loss
+        out["_stack_logits"], out["_stack_coords"] = inter_classes, inter_references
+        return out
+
+    # ---- KV-cached autoregressive inference -------------------------------------------------------
+    @torch.no_grad()
+    def forward_inference(self, samples, use_cache=True, support_graphs=None, support_mask=None, sync_every=8,
+                          teacher_stream=None):
+        """Generates until every sample has emitted <eos> (after >= 6 steps) or `tokenizer.seq_len` steps.
+        Token bookkeeping (roomformer_v2.py:521-598) runs on the device; the host only polls the
+        `unfinished` flags every `sync_every` steps, then trims to the step at which the reference's loop
+        would have stopped (identical outputs: steps after the stop only feed <pad> tokens).
+        `teacher_stream` (dict of (N,T) token/delta tensors) replaces the model's own feedback for parity tests."""
+        if not use_cache:
+            raise ValueError("the MI355X path always decodes with caches (use_cache=False is a debugging mode of the reference)")
+        enc = self._encode_images(samples)
+        dec = self.transformer.decoder
+        geo, vr, memory = enc["geo"], enc["valid_ratios"], enc["memory"]
+        N, dev = memory.shape[0], memory.device
+        tok = self.tokenizer
+        max_len = tok.seq_len if teacher_stream is None else min(tok.seq_len, teacher_stream["seq11"].shape[1])
+        min_len = 6
+        support = getattr(dec, "support_features", None)
+        smask = getattr(dec, "support_mask", None)
+        caches = []
+        for layer in dec.layers:
+            c = {"k": torch.zeros(N, self.seq_len, 256, device=dev), "v": torch.zeros(N, self.seq_len, 256, device=dev),
+                 "value": layer.cross_attn.project_value(memory, enc["pad_rows"]), "sup_k": None, "sup_v": None, "sup_kpm": None}
+            if support is not None:
+                ca = layer.support_attn
+                P = support.shape[1]
+                c["sup_k"] = torch.empty(N, P, 256, device=dev); c["sup_v"] = torch.empty(N, P, 256, device=dev)
+                s2 = support.contiguous().view(N * P, 256)
+                ops.gemm(s2, ca.in_proj_weight[256:], c["sup_k"], N * P, 256, 256, bias=ca.in_proj_bias[256:])
+                ops.gemm(s2, ca.in_proj_weight[512:], c["sup_v"], N * P, 256, 256, bias=ca.in_proj_bias[512:])
+                c["sup_kpm"] = smask.to(torch.uint8).contiguous() if smask is not None else None
+            caches.append(c)
+        ref_all = ops.sigmoid_fwd(self.query_embed.weight.detach().contiguous())            # (seq_len, 2)
+        toks = torch.full((4, N), tok.bos, dtype=torch.int64, device=dev)
+        deltas = torch.tensor([0.0, 1.0, 0.0, 1.0], device=dev).view(4, 1).repeat(1, N).contiguous()
+        unfinished = torch.ones(N, dtype=torch.int32, device=dev)
+        step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        out_logits = torch.zeros(N, max_len, self.num_classes, device=dev)
+        out_coords = torch.zeros(N, max_len, 2, device=dev)
+        out_hs = torch.zeros(N, max_len, 256, device=dev)
+        alive_after = torch.zeros(max_len, dtype=torch.int32, device=dev)   # #unfinished after each step
+        i, T = 0, max_len
+        while i < max_len:
+            if teacher_stream is not None:
+                toks = torch.stack([teacher_stream[k][:, i] for k in ("seq11", "seq12", "seq21", "seq22")]).contiguous()
+                deltas = torch.stack([teacher_stream[k][:, i] for k in ("delta_x1", "delta_x2", "delta_y1", "delta_y2")]).contiguous()
+            ref_i = ref_all[i].view(1, 1, 2).expand(N, 1, 2).contiguous()
+            hs, ref, cls = dec.decode_step(toks, deltas, ref_i, geo, vr, i, caches)
+            out_logits[:, i] = cls; out_coords[:, i] = ref.view(N, 2); out_hs[:, i] = hs.view(N, 256)
+            step_t.fill_(i)
+            ops.decode_next_tokens(cls, ref.view(N, 2), unfinished, toks, deltas, step_t, N, tok.num_bins, min_len,
+                                   tok.eos, tok.sep, tok.pad)
+            alive_after[i] = unfinished.sum()
+            i += 1
+            if teacher_stream is None and (i % sync_every == 0 or i == max_len):
+                alive = alive_after[:i].cpu()
+                done = (alive == 0).nonzero()
+                if len(done):
+                    T = int(done[0]) + 1
+                    break
+        else:
+            T = i
+        T = min(T, i)
+        incomplete = int(unfinished.sum()) if teacher_stream is None else 0
+        if incomplete > 0 and os.environ.get("WARN_INCOMPLETE_GENERATION", "1") == "1":
+            warnings.warn(f"{incomplete}/{N} sequences reached max_len={max_len} without predicting EOS.")
+        out = {"pred_logits": out_logits[:, :T], "pred_coords": out_coords[:, :T], "gen_out": None}
+        if self.room_class_embed is not None:
+            hs2 = out_hs[:, :T].contiguous()
+            rl = torch.empty(N, T, self.room_class_embed.weight.shape[0], device=dev)
+            ops.gemm(hs2.view(N * T, 256), self.room_class_embed.weight, rl, N * T, rl.shape[-1], 256,
+                     bias=self.room_class_embed.bias)
+            out["pred_room_logits"] = rl
+            out["anchors"] = self.query_embed.weight.detach()
+        return out
+
+    def _setup_caches(self, max_bs, max_src_len):
+        self.transformer._setup_caches(max_bs, self.seq_len, max_src_len, self.transformer.d_model, self.transformer.nhead,
+                                       self.transformer.level_embed.dtype, device=self.transformer.level_embed.device)
+
+
+def _nearest_mask(mask, h, w):
+    iy = torch.arange(h, device=mask.device) * mask.shape[1] // h
+    ix = torch.arange(w, device=mask.device) * mask.shape[2] // w
+    return mask[:, iy][:, :, ix]
+
+
+def build(args, train=True, tokenizer=None, cape_mode=False):
+    num_classes = 3 if not args.add_cls_token else 4
+    pad_idx = tokenizer.pad if tokenizer is not None else 0
+    backbone = build_backbone(args)
+    transformer = build_deforamble_transformer(args, pad_idx=pad_idx)
+    if getattr(args, "model_version", "v1") != "v1":
+        raise ValueError("only model_version v1 (RoomFormerV2) is on the CAPE path")
+    model = RoomFormerV2(backbone, transformer, num_classes=num_classes, num_queries=args.num_queries,
+                         num_polys=args.num_polys, num_feature_levels=args.num_feature_levels, aux_loss=args.aux_loss,
+                         with_poly_refine=args.with_poly_refine, masked_attn=args.masked_attn,
+                         semantic_classes=args.semantic_classes, seq_len=args.seq_len, tokenizer=tokenizer,
+                         use_anchor=args.use_anchor, patch_size=[1, 2][args.image_size == 512],
+                         freeze_anchor=getattr(args, "freeze_anchor", False),
+                         inject_cls_embed=getattr(args, "inject_cls_embed", False), cape_mode=cape_mode)
+    if not train:
+        return model
+    from .cape_losses import build_cape_criterion
+    criterion = build_cape_criterion(args, num_classes=num_classes)
+    return model, criterion

@@ -142,12 +142,14 @@ int cape_msda_bwd(const float* d_out, const float* value, const float* offw, con
  * ---------------------------------------------------------------------------------------------- */
 int cape_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse,
                   long long ldq, long long ldk, long long ldv, long long ldo,
+                  long long bsq, long long bsk, long long bsv, long long bso, /* batch strides (elements) */
                   int N, int H, int Lq, int Lk, float scale, int mask_mode, int causal_offset,
                   const uint8_t* kpm, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
                   cape_stream_t stream);
 int cape_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* O,
                   const float* lse, float* dQ, float* dK, float* dV,
                   long long ldq, long long ldk, long long ldv, long long ldo,
+                  long long bsq, long long bsk, long long bsv, long long bso,
                   int N, int H, int Lq, int Lk, float scale, int mask_mode, int causal_offset,
                   const uint8_t* kpm, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
                   cape_stream_t stream);
