@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- episodes/sec of the CAPE episodic TRAINING step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch of synthetic episodes: forward (backbone, encoder,
+support encoder, decoder), fused criterion, backward, gradient all-reduce (N > 1), global-norm clip,
+AdamW -- dropout ON (train mode), exact fp32 arithmetic.  Workload = BASELINE.json configs[1]:
+1-shot, 256x256, 17 keypoints, ResNet-50 + deformable transformer, 16 episodes x 2 queries per GPU.
+Weak scaling: every rank processes its own 16 episodes (pure data parallel, episodes are independent).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work: training FLOPs per episode at 256x256 (2 query images)
+GFLOP_PER_EPISODE_256 = 162.9
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def make_batches(tok, B, K, R, P, n_batches, seed, device):
+    from cape_amd.datasets import episodic_collate_fn
+    from cape_amd.datasets.synthetic import SyntheticEpisodes
+    ds = SyntheticEpisodes(tok, B * n_batches, R, P, K, seed=seed)
+    out = []
+    for i in range(n_batches):
+        b = episodic_collate_fn([ds[i * B + j] for j in range(B)])
+        out.append({"images": b["query_images"].to(device), "support_coords": b["support_coords"].to(device),
+                    "support_mask": b["support_masks"].to(device), "skeleton": b["support_skeletons"],
+                    "targets": {k: v.to(device) for k, v in b["query_targets"].items()}})
+    return out
+
+
+def cpu_baseline(args_ns, seconds_budget=25.0):
+    """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample of the
+    same workload: train step (fwd + loss + bwd + AdamW, dropout on) on 2 episodes x 2 queries at 256x256."""
+    from oracle import cape_ref, procweights, synth
+    cfg = cape_ref.Cfg()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "backbone.0.body.layer1" not in k and ".bn" not in k
+                                      and "downsample.1" not in k and "body.conv1" not in k and "attention_mask" not in k
+                                      and "pos_embed" not in k and ".pe" not in k)
+          for k, v in procweights.procedural_state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    b = synth.make_batch(1, 2, 2, 256, 17, cfg, n_invisible=(2, 0))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = cape_ref.cape_forward(sd, cfg, b["images"], b["support_coords"], b["support_mask"], b["targets"],
+                                    b["skeleton"], train=True)
+        _, _, total = cape_ref.criterion(out, b["targets"], cfg)
+        total.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 0.1)
+        opt.step()
+
+    step()                                   # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < seconds_budget and n < 8):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": 2.0 / dt, "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of 2 episodes x 2 queries, 256x256, 17 kpt (oracle/cape_ref.py, torch CPU fp32, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (configs[1]: 16)")
+    ap.add_argument("--image_size", type=int, default=256)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import cape_amd  # noqa: F401
+    from cape_amd.datasets import DiscreteTokenizerV2
+    from cape_amd.hip import functional as HF
+    from cape_amd.hip import ops
+    from cape_amd.models import build_model
+    from cape_amd.models.cape_model import build_cape_model
+    from cape_amd.models.train_cape_episodic import get_args_parser
+    from cape_amd.runtime.data_parallel import EpisodeDataParallel
+    from cape_amd.runtime.optimizer import ArenaAdamW
+
+    args = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(
+        ["--use_geometric_encoder", "--use_gcn_preenc", "--image_size", str(a.image_size)])
+    torch.manual_seed(1234)                      # identical random-init weights on every rank
+    tok = DiscreteTokenizerV2(44, args.seq_len)
+    base, crit = build_model(args, tokenizer=tok)
+    model = build_cape_model(args, base).to(device)
+    crit = crit.to(device)
+    model.train()
+    HF.Runtime.seed(1000 + rank, device)
+    opt = ArenaAdamW(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay,
+                     max_norm=args.clip_max_norm)
+    ddp = EpisodeDataParallel(model, opt) if world > 1 else None
+    B, K = a.episodes, 2
+    batches = make_batches(tok, B, K, a.image_size, 17, 4, seed=100 + rank, device=device)
+    rng = HF.Runtime.get_rng(device)
+    scale = 1.0 / world
+    last = {}
+
+    def step(i):
+        b = batches[i % len(batches)]
+        rng.advance()
+        out = model(samples=b["images"], support_coords=b["support_coords"], support_mask=b["support_mask"],
+                    targets=b["targets"], skeleton_edges=b["skeleton"])
+        total = crit(out, b["targets"])["_total"]
+        (total * scale).backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        opt.zero_grad()
+        last["loss"] = total.detach()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss = float(last["loss"])
+    assert np.isfinite(loss), "non-finite loss in the bench"
+    episodes = B * world * a.steps
+    value = episodes / dt
+    ms_per_step = dt / a.steps * 1e3
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        # dominant kernel = the fp32-MFMA implicit-GEMM family (csrc/gemm.hip: gemm_kernel<...>): every launch of
+        # the next steps is bracketed by HIP events on its own stream; achieved = sum(2MNK) / sum(duration)
+        ops.GemmProfiler.start()
+        nprof = min(2, a.steps)
+        for i in range(nprof):
+            step(a.warmup + a.steps + i)
+        r = ops.GemmProfiler.stop()
+        ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_kernel<BM,BN,AMODE,BMODE> (fp32 MFMA implicit GEMM, all instantiations)",
+                    "launches_per_step": r["launches"] // nprof,
+                    "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
+                    "gemm_ms_per_step": round(r["ms"] / nprof, 2),
+                    "gemm_gflop_per_step": round(r["flops"] / nprof / 1e9, 1)}
+    elif world > 1 and not a.no_roofline:
+        for i in range(min(2, a.steps)):         # keep the collectives of the profiled steps matched on all ranks
+            step(a.warmup + a.steps + i)
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        gflop_ep = GFLOP_PER_EPISODE_256 * (a.image_size / 256.0) ** 2
+        line = {
+            "metric": "episodes/sec (1-shot, 256x256, 17kpt) training step", "value": round(value, 3), "unit": "episodes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: 1-shot training step (fwd+loss+bwd+clip+AdamW, dropout on), "
+                                   f"{a.image_size}x{a.image_size}, 17 kpt, ResNet-50 + deformable transformer, "
+                                   f"{B} episodes x 2 queries per GPU", "episodes_per_gpu": B, "queries_per_episode": K,
+                       "image_size": a.image_size, "global_batch_episodes": B * world, "parallelism": f"dp{world}",
+                       "weights": "random init (no checkpoint offline)"},
+            "loss": round(loss, 4),
+            "model_tflops": round(value * gflop_ep / 1e3, 2),
+            "model_frac_of_f32_mfma_peak": round(value * gflop_ep / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

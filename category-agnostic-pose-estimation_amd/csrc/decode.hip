@@ -8,6 +8,7 @@ namespace {
 __global__ void next_tokens_kernel(const float* cls_logits, const float* reg, int32_t* unfinished, int64_t* tok,
                                    float* delta, const int32_t* step, int N, int nb, int min_len, int eos_id, int sep_id,
                                    int pad_id) {
+#pragma clang fp contract(off)   // the reference rounds x*43 before floor/subtract: no FMA contraction here
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
   const int i = step[0];

@@ -73,6 +73,25 @@ def pick_split_k(M, N, K):
     return int(max(1, min(want, ktiles // 8 if ktiles >= 16 else 1, 64)))
 
 
+class GemmProfiler:
+    """Optional per-launch timing of the GEMM family (bench.py's roofline leg): HIP events recorded on the
+    stream the kernel is launched on, algorithmic flops = 2*M*N*K per launch."""
+    enabled = False
+    records = []
+
+    @classmethod
+    def start(cls):
+        cls.records, cls.enabled = [], True
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        torch.cuda.synchronize()
+        flops = sum(r[2] for r in cls.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in cls.records)
+        return {"launches": len(cls.records), "flops": flops, "ms": ms}
+
+
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
@@ -110,6 +129,13 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         assert bias.numel() >= N
     if scale is not None:
         assert scale.numel() >= N
+    if GemmProfiler.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
+        e1.record()
+        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K))
+        return
     lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
 
 

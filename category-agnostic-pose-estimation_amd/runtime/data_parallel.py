@@ -1,0 +1,117 @@
+"""Episode data parallelism: one process per GPU, model replicated, episodes sharded by rank, ONE
+exchange per optimizer step -- the gradient all-reduce (sum of per-rank grads of loss/world_size) over
+RCCL/xGMI on the flat gradient arenas.  The reference has no distributed training; this
+is the MI355X-native design for it:
+
+  * gradients already live in contiguous slabs (runtime/arena.py), so a bucket is just a [lo, hi) range --
+    no flatten/unflatten copies;
+  * buckets are cut in *reverse* parameter order (~ the order backward produces them) at ~25 MB: on the
+    fully-connected xGMI node RCCL moves 1/8 of a bucket over each of the 7 links concurrently, and 25 MB
+    keeps each launch in the bandwidth regime while leaving several buckets to overlap with backward;
+  * a bucket is launched on a side stream as soon as the last of its parameters has accumulated its
+    gradient (post-accumulate-grad hooks); `finish()` joins the stream before the optimizer step;
+  * micro-batches of gradient accumulation skip the exchange (`no_sync`), the boundary micro-batch reduces
+    the accumulated sum;
+  * parameters that never receive gradients are outside the arenas, identically on all ranks.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+
+class EpisodeDataParallel:
+    def __init__(self, model, optimizer, bucket_mb=25.0, process_group=None):
+        self.model, self.opt, self.pg = model, optimizer, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.sync_enabled = True
+        self.buckets = []           # (arena, lo, hi, [param indices])
+        self._pending = {}
+        self._handles = []
+        self.comm_stream = torch.cuda.Stream() if (torch.cuda.is_available() and self.world > 1) else None
+        if self.world > 1:
+            self._broadcast_parameters()
+            self._build_buckets(int(bucket_mb * (1 << 20) / 4))
+            self._install_hooks()
+
+    def _broadcast_parameters(self):
+        for a in self.opt.arenas:
+            if a.numel:
+                dist.broadcast(a.data, src=0, group=self.pg)
+        for m in (self.model,):
+            for b in m.buffers():
+                if b.is_floating_point():
+                    dist.broadcast(b, src=0, group=self.pg)
+
+    def _build_buckets(self, bucket_elems):
+        for a in self.opt.arenas:
+            n = len(a.params)
+            hi_i = n
+            while hi_i > 0:
+                lo_i = hi_i - 1
+                hi = a.offsets[hi_i] if hi_i < n else a.numel
+                while lo_i > 0 and hi - a.offsets[lo_i - 1] <= bucket_elems:
+                    lo_i -= 1
+                self.buckets.append((a, a.offsets[lo_i], hi, list(range(lo_i, hi_i))))
+                hi_i = lo_i
+
+    def _install_hooks(self):
+        self._bucket_of = {}
+        for bi, (a, lo, hi, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                p = a.params[i]
+                self._bucket_of[id(p)] = bi
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+        self._reset_pending()
+
+    def _reset_pending(self):
+        self._pending = {bi: len(b[3]) for bi, b in enumerate(self.buckets)}
+        self._launched = set()
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            if not self.sync_enabled:
+                return
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        if bi in self._launched:
+            return
+        self._launched.add(bi)
+        a, lo, hi, _ = self.buckets[bi]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(a.grad[lo:hi], group=self.pg)
+        else:
+            self._handles.append(dist.all_reduce(a.grad[lo:hi], group=self.pg, async_op=True))
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        old, self.sync_enabled = self.sync_enabled, False
+        try:
+            yield
+        finally:
+            self.sync_enabled = old
+
+    def finish(self):
+        """Call after the boundary micro-batch's backward: launches what hooks did not (parameters whose
+        gradient was not produced this step still hold their zeros) and joins the communication."""
+        if self.world < 2:
+            return
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._reset_pending()
+
+    @property
+    def loss_scale(self):
+        """Multiply the loss by this so that the SUM all-reduce yields the mean gradient."""
+        return 1.0 / self.world

@@ -1,0 +1,44 @@
+"""One tiny invocation of the hot path on cuda:0 checked against the CPU oracle (driver smoke test)."""
+import argparse
+import os
+import sys
+
+import torch
+
+
+def run():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import cape_ref, procweights, synth            # the checker, not the product
+    from cape_amd.datasets import DiscreteTokenizerV2
+    from cape_amd.models import build_model
+    from cape_amd.models.cape_model import build_cape_model
+    from cape_amd.models.train_cape_episodic import get_args_parser
+    from cape_amd.hip import lib
+    assert lib.abi_version() == 1
+    cfg = cape_ref.Cfg()
+    sd = procweights.procedural_state_dict()
+    args = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(["--use_geometric_encoder", "--use_gcn_preenc"])
+    tok = DiscreteTokenizerV2(44, args.seq_len)
+    base, crit = build_model(args, tokenizer=tok)
+    model = build_cape_model(args, base)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    crit = crit.to("cuda:0")
+    b = synth.make_batch(3, 1, 2, 64, 9, cfg, n_invisible=(2,))
+    dev = {k: (v.to("cuda:0") if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    tg = {k: v.to("cuda:0") for k, v in b["targets"].items()}
+    out = model(samples=dev["images"], support_coords=dev["support_coords"], support_mask=dev["support_mask"], targets=tg,
+                skeleton_edges=b["skeleton"])
+    total = crit(out, tg)["_total"]
+    total.backward()
+    ref = cape_ref.cape_forward(sd, cfg, b["images"], b["support_coords"], b["support_mask"], b["targets"], b["skeleton"])
+    _, _, ref_total = cape_ref.criterion(ref, b["targets"], cfg)
+    err = (out["pred_logits"].detach().cpu() - ref["pred_logits"]).abs().max().item()
+    assert err < 1e-3, f"smoke: logits differ from the oracle by {err}"
+    assert abs(float(total) - float(ref_total)) < 5e-3, (float(total), float(ref_total))
+    tok.seq_len = 8
+    pred = model.forward_inference(dev["images"], dev["support_coords"], dev["support_mask"], b["skeleton"])
+    assert pred["logits"].shape[0] == 2 and torch.isfinite(pred["logits"]).all()
+    print(f"smoke ok: max |logit - oracle| = {err:.2e}, loss {float(total):.4f} (oracle {float(ref_total):.4f})")
