@@ -42,13 +42,30 @@ def make_batches(tok, B, K, R, P, n_batches, seed, device):
     return out
 
 
-def cpu_baseline(args_ns, seconds_budget=25.0):
+def host_cores():
+    """CPU share of this process: affinity mask, cgroup quota, capped at the GPU box's documented share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(args_ns, seconds_budget=20.0):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample of the
     same workload: train step (fwd + loss + bwd + AdamW, dropout on) on 2 episodes x 2 queries at 256x256."""
     from oracle import cape_ref, procweights, synth
     cfg = cape_ref.Cfg()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle train step on {cores} host threads")
     sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "backbone.0.body.layer1" not in k and ".bn" not in k
                                       and "downsample.1" not in k and "body.conv1" not in k and "attention_mask" not in k
                                       and "pos_embed" not in k and ".pe" not in k)
@@ -66,11 +83,14 @@ def cpu_baseline(args_ns, seconds_budget=25.0):
         torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 0.1)
         opt.step()
 
+    tw = time.time()
     step()                                   # warm-up
+    log(f"cpu_baseline: warm-up step {time.time() - tw:.1f} s")
     n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < seconds_budget and n < 8):
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
         step()
         n += 1
+        log(f"cpu_baseline: step {n} at {time.time() - t0:.1f} s")
     dt = (time.time() - t0) / n
     return {"value": 2.0 / dt, "unit": "episodes/s", "cores": cores, "kind": "port",
             "sample": f"{n} train steps of 2 episodes x 2 queries, 256x256, 17 kpt (oracle/cape_ref.py, torch CPU fp32, {cores} threads)"}
@@ -145,9 +165,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model built, {len(batches)} batches of {B} episodes resident; warm-up x{a.warmup}")
     for i in range(a.warmup):
         step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     sync()
+    log(f"timing {a.steps} steps")
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
@@ -157,6 +182,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    log(f"timed region {dt:.3f} s")
     loss = float(last["loss"])
     assert np.isfinite(loss), "non-finite loss in the bench"
     episodes = B * world * a.steps
