@@ -193,11 +193,15 @@ def main():
     if not a.no_roofline and rank == 0:
         # dominant kernel = the fp32-MFMA implicit-GEMM family (csrc/gemm.hip: gemm_kernel<...>): every launch of
         # the next steps is bracketed by HIP events on its own stream; achieved = sum(2MNK) / sum(duration)
-        ops.GemmProfiler.start()
         nprof = min(2, a.steps)
+        ops.GemmProfiler.start()
         for i in range(nprof):
             step(a.warmup + a.steps + i)
         r = ops.GemmProfiler.stop()
+        if os.environ.get("CAPE_BENCH_GEMM_TABLE"):
+            rows = sorted(r["table"].items(), key=lambda kv: -kv[1][1])
+            for shape, (cnt, ms, fl) in rows[:40]:
+                log(f"gemm M,N,K,am,bm,sk={shape} calls/step {cnt // nprof} ms/step {ms / nprof:.3f} TF/s {fl / (ms * 1e-3) / 1e12:.1f}")
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,

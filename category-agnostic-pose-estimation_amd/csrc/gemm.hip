@@ -395,36 +395,41 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
 // column sums: out[n] (+)= sum_m X[m][n].  grid (ceil(N/64), row splits); one column per lane,
 // 4 waves of a block stride over rows; partials combined through LDS then one atomic per column.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) colsum_kernel(const float* X, long long ldx, int M, int N, float* out,
-                                                      int rows_per_block) {
+__global__ void __launch_bounds__(256) colsum_kernel(const float* X, long long ldx, long long batch_stride, int rows_per_batch,
+                                                      long long M, int N, float* out, long long rows_per_block) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
-  const int r0 = blockIdx.y * rows_per_block;
-  const int r1 = min(M, r0 + rows_per_block);
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
   if (col < N)
-    for (int r = r0 + w; r < r1; r += 4) s += X[(long long)r * ldx + col];
+    for (long long r = r0 + w; r < r1; r += 4) {
+      const long long b = r / rows_per_batch, rr = r - b * rows_per_batch;
+      s += X[b * batch_stride + rr * ldx + col];
+    }
   part[w][lane] = s;
   __syncthreads();
   if (w == 0 && col < N) atomicAdd(&out[col], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 
-extern "C" int cape_colsum_f32(const float* X, long long ldx, int M, int N, float* out, int accumulate,
-                               cape_stream_t stream) {
-  CAPE_REQUIRE(X && out && M >= 0 && N > 0, "cape_colsum_f32: bad arguments");
+extern "C" int cape_colsum_f32(const float* X, long long ldx, int nbatch, long long batch_stride, int M, int N, float* out,
+                               int accumulate, cape_stream_t stream) {
+  CAPE_REQUIRE(X && out && M >= 0 && N > 0 && nbatch >= 1, "cape_colsum_f32: bad arguments");
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, as_stream(stream));
     if (e != hipSuccess) return cape_set_error("cape_colsum_f32: memset: %s", hipGetErrorString(e));
   }
   if (M == 0) return 0;
+  const long long rows = (long long)M * nbatch;
   const int gx = (N + 63) / 64;
-  int splits = (M + 255) / 256;
-  const int max_splits = (2048 + gx - 1) / gx;
+  long long splits = (rows + 127) / 128;
+  const long long max_splits = (2048 + gx - 1) / gx;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  const int rpb = (M + splits - 1) / splits;
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, splits), dim3(256), 0, as_stream(stream), X, ldx, M, N, out, rpb);
+  const long long rpb = (rows + splits - 1) / splits;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), X, ldx, batch_stride, M, rows, N,
+                     out, rpb);
   CAPE_LAUNCH_CHECK("cape_colsum_f32");
   return 0;
 }

@@ -207,6 +207,141 @@ __global__ void __launch_bounds__(256) msda_bwd_kernel(const float* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// backward, LDS-accumulating form.  One block per (image, head, level group): the d_value slab of that
+// (image, head) for the group's levels lives in LDS (level 0: H0*W0*128 B; remaining levels together),
+// every tap is an LDS atomic (ds_add_f32) instead of a memory-side atomic, and the slab is written back
+// with plain stores (exclusive owner -> d_value needs no zero fill).  8 query slots x 32 channels per block.
+// d_aw is emitted raw (gradient w.r.t. the softmaxed weight); msda_softmax_bwd_kernel turns it into the
+// logit gradient afterwards (the softmax spans samples handled by both groups).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) msda_bwd_lds_kernel(const float* __restrict__ d_out, const float* __restrict__ value,
+                                                            const float* __restrict__ offw, const float* __restrict__ ref,
+                                                            float* __restrict__ d_value, float* __restrict__ d_offw,
+                                                            float* __restrict__ d_ref, Levels lv, int N, int S, int Lq, int L,
+                                                            int P, int lvl_begin, int lvl_end) {
+  extern __shared__ __attribute__((aligned(16))) float dval[];     // [npix][32]
+  const int n = blockIdx.x >> 3, h = blockIdx.x & 7;
+  const int pix0 = sel4(lv.start, lvl_begin);
+  const int pix1 = (lvl_end < L) ? sel4(lv.start, lvl_end) : S;
+  const int npix = pix1 - pix0;
+  for (int i = threadIdx.x; i < npix * HD; i += 256) dval[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 31;
+  const int slot = threadIdx.x >> 5;                               // 8 query slots
+  const int LP = L * P;
+  const int j = c & 15;
+  const int rowlen = HEADS * LP * 3;
+  const float* vbase = value + (long long)n * S * CH + h * HD + c;
+  const int jb = lvl_begin * P, je = lvl_end * P;                  // this group's sample range
+  const int iters = (Lq + 7) >> 3;
+  for (int it = 0; it < iters; ++it) {
+    const int q = it * 8 + slot;
+    const bool qlive = q < Lq;                                     // half-wave uniform
+    const long long qrow = (long long)n * Lq + (qlive ? q : 0);
+    const float* ow = offw + qrow * rowlen;
+    float px = 0.f, py = 0.f, lg = -INFINITY;
+    int l_own = 0;
+    if (j < LP) {
+      l_own = j / P;
+      const float rx = ref[(qrow * L + l_own) * 2 + 0], ry = ref[(qrow * L + l_own) * 2 + 1];
+      const float ox = ow[(h * LP + j) * 2 + 0], oy = ow[(h * LP + j) * 2 + 1];
+      const float Wf = (float)sel4(lv.W, l_own), Hf = (float)sel4(lv.H, l_own);
+      px = (rx + ox / Wf) * Wf - 0.5f;
+      py = (ry + oy / Hf) * Hf - 0.5f;
+      lg = ow[HEADS * LP * 2 + h * LP + j];
+    }
+    float mx = lg;
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+    const float e = __expf(lg - mx);
+    float sm = e;
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+    const float aw = e / sm;
+    const float go = qlive ? d_out[qrow * CH + h * HD + c] : 0.f;
+    float my_daw = 0.f, my_dpx = 0.f, my_dpy = 0.f;
+    for (int jj = jb; jj < je; ++jj) {
+      const int src = (lane & 32) | jj;
+      const float x = __shfl(px, src, 64), y = __shfl(py, src, 64), a = __shfl(aw, src, 64);
+      const int l = __shfl(l_own, src, 64);
+      const int W = sel4(lv.W, l), H = sel4(lv.H, l);
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const int lofs = sel4(lv.start, l);
+      const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+      const bool ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
+      float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+      const float ga = go * a;
+      if (qlive) {
+        if (ya && xa) { const int p_ = lofs + y0 * W + x0; v00 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * (1.f - fx) * (1.f - fy)); }
+        if (ya && xb) { const int p_ = lofs + y0 * W + x0 + 1; v01 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * fx * (1.f - fy)); }
+        if (yb && xa) { const int p_ = lofs + (y0 + 1) * W + x0; v10 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * (1.f - fx) * fy); }
+        if (yb && xb) { const int p_ = lofs + (y0 + 1) * W + x0 + 1; v11 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * fx * fy); }
+      }
+      const float samp = (1.f - fy) * ((1.f - fx) * v00 + fx * v01) + fy * ((1.f - fx) * v10 + fx * v11);
+      const float dsx = (1.f - fy) * (v01 - v00) + fy * (v11 - v10);
+      const float dsy = (1.f - fx) * (v10 - v00) + fx * (v11 - v01);
+      const float r_aw = half_sum32(go * samp);
+      const float r_px = half_sum32(ga * dsx);
+      const float r_py = half_sum32(ga * dsy);
+      if (j == jj) { my_daw = r_aw; my_dpx = r_px; my_dpy = r_py; }
+    }
+    const bool own = qlive && c < 16 && j >= jb && j < je;
+    float* dow = d_offw + qrow * rowlen;
+    if (own) {
+      dow[(h * LP + j) * 2 + 0] = my_dpx;
+      dow[(h * LP + j) * 2 + 1] = my_dpy;
+      dow[HEADS * LP * 2 + h * LP + j] = my_daw;                   // raw d_aw; softmax backward runs afterwards
+    }
+    if (d_ref) {
+      float rx = own ? my_dpx * (float)sel4(lv.W, l_own) : 0.f;
+      float ry = own ? my_dpy * (float)sel4(lv.H, l_own) : 0.f;
+      if (P == 4) {
+        rx += __shfl_xor(rx, 1, 64); rx += __shfl_xor(rx, 2, 64);
+        ry += __shfl_xor(ry, 1, 64); ry += __shfl_xor(ry, 2, 64);
+        if (own && (j & 3) == 0) {
+          atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 0], rx);
+          atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 1], ry);
+        }
+      } else if (own) {
+        atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 0], rx);
+        atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 1], ry);
+      }
+    }
+  }
+  __syncthreads();
+  float* dvb = d_value + ((long long)n * S + pix0) * CH + h * HD;
+  for (int i = threadIdx.x; i < npix * 8; i += 256) {
+    const int p_ = i >> 3, c4 = (i & 7) * 4;
+    *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c4) = *reinterpret_cast<const float4*>(&dval[p_ * HD + c4]);
+  }
+}
+
+// dlogit = aw * (d_aw - sum_k aw_k d_aw_k) in place on the logit slots of d_offw; thread = (query, head)
+__global__ void msda_softmax_bwd_kernel(const float* __restrict__ offw, float* __restrict__ d_offw, long long rows, int LP) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * HEADS) return;
+  const long long qrow = i >> 3;
+  const int h = (int)(i & 7);
+  const int rowlen = HEADS * LP * 3;
+  const float* lg = offw + qrow * rowlen + HEADS * LP * 2 + h * LP;
+  float* dg = d_offw + qrow * rowlen + HEADS * LP * 2 + h * LP;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) if (k < LP) mx = fmaxf(mx, lg[k]);
+  float e[16], d[16], sm = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { e[k] = k < LP ? __expf(lg[k] - mx) : 0.f; d[k] = k < LP ? dg[k] : 0.f; sm += e[k]; }
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { e[k] /= sm; dot += e[k] * d[k]; }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) if (k < LP) dg[k] = e[k] * (d[k] - dot);
+}
+
 int fill_levels(Levels& lv, const int* shapes, const int* level_start, int L, int S) {
   CAPE_REQUIRE(L >= 1 && L <= 4, "cape_msda: L=%d must be in 1..4", L);
   long long tot = 0;
@@ -251,6 +386,38 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
   if (N <= 0 || Lq <= 0) return 0;
   Levels lv;
   if (fill_levels(lv, shapes, level_start, L, S)) return 1;
+  // LDS-accumulating form when the (image, head) gradient slabs fit: group A = level 0, group B = the rest
+  const long long pixA = (long long)lv.H[0] * lv.W[0], pixB = (long long)S - pixA;
+  const size_t ldsA = (size_t)pixA * HD * sizeof(float), ldsB = (size_t)pixB * HD * sizeof(float);
+  const size_t kMaxLds = 144 * 1024;
+  if (L >= 2 && ldsA <= kMaxLds && ldsB <= kMaxLds && (long long)N * HEADS < (1ll << 31)) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+      if (e != hipSuccess) return cape_set_error("cape_msda_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_done = true;
+    }
+    if (d_ref) {
+      hipError_t e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
+      if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(256), ldsA, as_stream(stream), d_out, value, offw,
+                       ref, d_value, d_offw, d_ref, lv, N, S, Lq, L, P, 0, 1);
+    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(256), ldsB, as_stream(stream), d_out, value, offw,
+                       ref, d_value, d_offw, d_ref, lv, N, S, Lq, L, P, 1, L);
+    const long long rows = (long long)N * Lq;
+    hipLaunchKernelGGL(msda_softmax_bwd_kernel, dim3((unsigned)((rows * HEADS + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       offw, d_offw, rows, L * P);
+    CAPE_LAUNCH_CHECK("cape_msda_bwd(lds)");
+    return 0;
+  }
+  // fallback: memory-side atomics straight into d_value (any geometry); d_value / d_ref are zeroed here
+  {
+    hipError_t e = hipMemsetAsync(d_value, 0, sizeof(float) * (size_t)N * S * CH, as_stream(stream));
+    if (e == hipSuccess && d_ref) e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
+    if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
+  }
   const long long waves = (long long)N * Lq * 4;
   const long long blocks = (waves + 3) / 4;
   CAPE_REQUIRE(blocks < (1ll << 31), "cape_msda_bwd: grid too large");

@@ -10,8 +10,35 @@ from . import ops
 
 
 class Runtime:
-    """Per-process runtime state shared by the Functions: dropout RNG state on device."""
+    """Per-process runtime state shared by the Functions: dropout RNG state on device, and the
+    weight-gradient sink: when parameters own gradient-arena views (runtime/arena.py) the wgrad kernels
+    accumulate straight into them (GEMM epilogue `C += ...` / atomics) instead of materialising a tensor that
+    autograd would add afterwards, and they run on a side stream so that they fill the idle CUs of the
+    data-gradient chain's kernel tails.  `on_param_grad` callbacks let the data-parallel layer launch a
+    bucket's all-reduce as soon as its gradients have been enqueued."""
     rng = None
+    direct_grad = False
+    side = None
+    on_param_grad = []
+
+    @classmethod
+    def side_stream(cls):
+        if cls.side is None:
+            cls.side = torch.cuda.Stream()
+        return cls.side
+
+    @classmethod
+    def join(cls):
+        """Make the current stream wait for all enqueued side-stream work (call before the optimizer step)."""
+        if cls.side is not None:
+            torch.cuda.current_stream().wait_stream(cls.side)
+
+    @classmethod
+    def notify(cls, *params):
+        for cb in cls.on_param_grad:
+            for p in params:
+                if p is not None:
+                    cb(p)
 
     @classmethod
     def get_rng(cls, device):
@@ -26,6 +53,46 @@ class Runtime:
 
 def _c(t):
     return t if (t is None or t.is_contiguous()) else t.contiguous()
+
+
+def _sink(p):
+    """Gradient-arena view of parameter `p` (or of the parameter `p` is a plain view of), else None."""
+    if not Runtime.direct_grad or p is None or not p.requires_grad:
+        return None
+    if isinstance(p, torch.nn.Parameter):
+        return p.grad
+    base = p._base
+    if isinstance(base, torch.nn.Parameter) and base.grad is not None and base.requires_grad:
+        off = p.storage_offset() - base.storage_offset() + base.grad.storage_offset()
+        return torch.as_strided(base.grad, p.shape, p.stride(), off)
+    return None
+
+
+def _param_of(p):
+    if isinstance(p, torch.nn.Parameter):
+        return p
+    return p._base if (p is not None and isinstance(p._base, torch.nn.Parameter)) else None
+
+
+class _Side:
+    """with _Side(tensors...): kernels inside run on the side stream, ordered after the current stream's work so
+    far; the listed tensors are kept alive for that stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        self.s = Runtime.side_stream()
+        self.s.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.s)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.ctx.__exit__(*a)
+        for t in self.tensors:
+            t.record_stream(self.s)
+        return False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -45,6 +112,7 @@ class LinearFn(torch.autograd.Function):
         ops.gemm(x2, weight, y, M, N, K, ldb=weight.stride(0), bias=bias, residual=res2, relu=relu, dropout_p=dropout_p,
                  rng=rng, rng_stream=rng_stream)
         ctx.save_for_backward(x2, weight, y if (relu or dropout_p > 0) else None)
+        ctx.w_ref, ctx.b_ref = weight, bias
         ctx.meta = (relu, dropout_p, bias is not None, residual is not None, x.shape, M, N, K)
         return y.view(*x.shape[:-1], N)
 
@@ -62,11 +130,22 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             ops.gemm(dpre, weight, dx, M, K, N, a_mode=0, b_mode=1, ldb=weight.stride(0))
             dx = dx.view(xshape)
-        if ctx.needs_input_grad[1]:
+        wsink, bsink = _sink(ctx.w_ref), _sink(ctx.b_ref)
+        need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        if (need_w and wsink is not None) or (need_b and bsink is not None):
+            with _Side(dpre, x2):
+                if need_w and wsink is not None:
+                    ops.gemm(dpre, x2, wsink, N, K, M, a_mode=1, b_mode=1, lda=N, ldb=K, ldc=wsink.stride(0), accumulate=True,
+                             split_k=ops.pick_split_k(N, K, M))
+                if need_b and bsink is not None:
+                    ops.colsum(dpre, M, N, bsink)
+            Runtime.notify(_param_of(ctx.w_ref) if (need_w and wsink is not None) else None,
+                           _param_of(ctx.b_ref) if (need_b and bsink is not None) else None)
+        if need_w and wsink is None:
             dw = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
             ops.gemm(dpre, x2, dw, N, K, M, a_mode=1, b_mode=1, lda=N, ldb=K, accumulate=True,
                      split_k=ops.pick_split_k(N, K, M))
-        if has_bias and ctx.needs_input_grad[2]:
+        if need_b and bsink is None:
             db = torch.zeros(N, dtype=torch.float32, device=dy.device)
             ops.colsum(dpre, M, N, db)
         if has_res and ctx.needs_input_grad[3]:
@@ -91,6 +170,7 @@ class LinearCat2Fn(torch.autograd.Function):
         ops.gemm(x2, w1, y, M, N1, K, bias=b1, ldc=N1 + N2)
         ops.gemm(x2, w2, y[:, N1:], M, N2, K, bias=b2, ldc=N1 + N2)
         ctx.save_for_backward(x2, w1, w2)
+        ctx.refs = (w1, b1, w2, b2)
         ctx.meta = (x.shape, M, N1, N2, K)
         return y.view(*x.shape[:-1], N1 + N2)
 
@@ -107,6 +187,16 @@ class LinearCat2Fn(torch.autograd.Function):
             ops.gemm(dy2, w1, dx, M, K, N1, a_mode=0, b_mode=1, lda=NT)
             ops.gemm(dy2[:, N1:], w2, dx, M, K, N2, a_mode=0, b_mode=1, lda=NT, accumulate=True)
             dx = dx.view(xshape)
+        sinks = [_sink(t) for t in ctx.refs]
+        if all(k is not None for k in sinks):
+            with _Side(dy2, x2):
+                ops.gemm(dy2, x2, sinks[0], N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M))
+                ops.gemm(dy2[:, N1:], x2, sinks[2], N2, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True,
+                         split_k=ops.pick_split_k(N2, K, M))
+                ops.colsum(dy2, M, N1, sinks[1], ldx=NT)
+                ops.colsum(dy2[:, N1:], M, N2, sinks[3], ldx=NT)
+            Runtime.notify(*[_param_of(t) for t in ctx.refs])
+            return dx, None, None, None, None
         dw1 = torch.zeros(N1, K, dtype=torch.float32, device=dev)
         dw2 = torch.zeros(N2, K, dtype=torch.float32, device=dev)
         ops.gemm(dy2, x2, dw1, N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M))
@@ -151,6 +241,7 @@ class ConvFn(torch.autograd.Function):
         else:
             ops.gemm(x, wp, y, M, O, K, a_mode=2, b_mode=0, conv=geom, scale=scale, bias=shift, residual=res, relu=relu)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.w_ref, ctx.shift_ref = weight, shift
         ctx.meta = (geom, dense, relu, shift is not None, residual is not None)
         return y
 
@@ -175,18 +266,37 @@ class ConvFn(torch.autograd.Function):
                 ops.gemm(dpre, wp, dx, M, C, O, a_mode=0, b_mode=1)
             else:
                 ops.gemm(dpre, wp, dx, N * H * W, C, KH * KW * O, a_mode=3, b_mode=2, conv=geom)
-        if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(O, KH, KW, C, dtype=torch.float32, device=dy.device)
+        wsink = _sink(ctx.w_ref)
+        ssink = _sink(ctx.shift_ref) if (has_shift and ctx.needs_input_grad[3]) else None
+        need_w = ctx.needs_input_grad[1]
+        need_s = has_shift and ctx.needs_input_grad[3]
+        src_s = None
+        if need_s:
+            src_s = dpre if scale is None else (dres if dres is not None else _mask_only(dy, y, relu))
+
+        def wgrad(dst_phys):
             if dense:
-                ops.gemm(dpre, x, dwp, O, C, M, a_mode=1, b_mode=1, lda=O, ldb=C, accumulate=True,
+                ops.gemm(dpre, x, dst_phys, O, C, M, a_mode=1, b_mode=1, lda=O, ldb=C, accumulate=True,
                          split_k=ops.pick_split_k(O, C, M))
             else:
-                ops.gemm(dpre, x, dwp, O, K, M, a_mode=1, b_mode=3, lda=O, conv=geom, accumulate=True,
+                ops.gemm(dpre, x, dst_phys, O, K, M, a_mode=1, b_mode=3, lda=O, conv=geom, accumulate=True,
                          split_k=ops.pick_split_k(O, K, M))
+
+        if (need_w and wsink is not None) or (need_s and ssink is not None):
+            with _Side(dpre, x, src_s):
+                if need_w and wsink is not None:
+                    wgrad(_w_phys(wsink))
+                if need_s and ssink is not None:
+                    ops.colsum(src_s, M, O, ssink)
+            Runtime.notify(_param_of(ctx.w_ref) if (need_w and wsink is not None) else None,
+                           _param_of(ctx.shift_ref) if (need_s and ssink is not None) else None)
+        if need_w and wsink is None:
+            dwp = torch.zeros(O, KH, KW, C, dtype=torch.float32, device=dy.device)
+            wgrad(dwp)
             dw = dwp.permute(0, 3, 1, 2)
-        if has_shift and ctx.needs_input_grad[3]:
+        if need_s and ssink is None:
             dshift = torch.zeros(O, dtype=torch.float32, device=dy.device)
-            ops.colsum(dpre if scale is None else (dres if dres is not None else _mask_only(dy, y, relu)), M, O, dshift)
+            ops.colsum(src_s, M, O, dshift)
         return dx, dw, None, dshift, dres, None, None, None
 
 
@@ -216,6 +326,7 @@ class AddLayerNormFn(torch.autograd.Function):
         out, mean, rstd, out_pos = ops.add_layernorm_fwd(x, y, gamma, beta, pos=pos, dropout_p=dropout_p, rng=rng,
                                                          rng_stream=rng_stream)
         ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.refs = (gamma, beta)
         ctx.meta = (dropout_p, rng_stream, pos is not None)
         if pos is None:
             return out
@@ -230,11 +341,16 @@ class AddLayerNormFn(torch.autograd.Function):
             d_pos_only = d_out
         d_out, d_out_pos = _c(d_out), _c(d_out_pos)
         C = x.shape[-1]
-        dg = torch.zeros(C, dtype=torch.float32, device=x.device)
-        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        gs, bs = _sink(ctx.refs[0]), _sink(ctx.refs[1])
+        direct = gs is not None and bs is not None
+        dg = gs if direct else torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = bs if direct else torch.zeros(C, dtype=torch.float32, device=x.device)
         rng = Runtime.get_rng(x.device) if p > 0 else None
         dx, dy = ops.add_layernorm_bwd(d_out, d_out_pos, x, y, gamma, mean, rstd, dg, db, dropout_p=p, rng=rng,
                                        rng_stream=stream)
+        if direct:
+            Runtime.notify(_param_of(ctx.refs[0]), _param_of(ctx.refs[1]))
+            dg = db = None
         dpos = None
         if has_pos and ctx.needs_input_grad[4]:
             dpos = d_out_pos if d_out_pos is not None else None
@@ -278,6 +394,7 @@ class LevelGroupNormFn(torch.autograd.Function):
             assert x.shape[1] == h and x.shape[2] == w
             stats.append(ops.groupnorm_fwd(x, gammas[l], betas[l], out[:, geo.starts[l]:], geo.S * C, N, h * w, C))
         ctx.geo = geo
+        ctx.refs = (tuple(gammas), tuple(betas))
         ctx.save_for_backward(*xs, *gammas, *[s for st in stats for s in st])
         return out
 
@@ -292,10 +409,15 @@ class LevelGroupNormFn(torch.autograd.Function):
         dxs, dgs, dbs = [], [], []
         for l in range(L):
             h, w = geo.shapes[l]
-            dg = torch.zeros(C, dtype=torch.float32, device=d_out.device)
-            db = torch.zeros(C, dtype=torch.float32, device=d_out.device)
+            gs, bs = _sink(ctx.refs[0][l]), _sink(ctx.refs[1][l])
+            direct = gs is not None and bs is not None
+            dg = gs if direct else torch.zeros(C, dtype=torch.float32, device=d_out.device)
+            db = bs if direct else torch.zeros(C, dtype=torch.float32, device=d_out.device)
             dx = ops.groupnorm_bwd(d_out[:, geo.starts[l]:], S * C, xs[l], gammas[l], st[2 * l], st[2 * l + 1], dg, db, N,
                                    h * w, C)
+            if direct:
+                Runtime.notify(_param_of(ctx.refs[0][l]), _param_of(ctx.refs[1][l]))
+                dg = db = None
             dxs.append(dx); dgs.append(dg); dbs.append(db)
         return (None, *dxs, *dgs, *dbs)
 
@@ -317,6 +439,7 @@ class LevelPosFn(torch.autograd.Function):
             ops.pos_sine_level(_c(m), level_embed[l], out[:, geo.starts[l]:], geo.S * C, N, h, w, C)
         ctx.geo = geo
         ctx.N = N
+        ctx.le_ref = level_embed
         return out
 
     @staticmethod
@@ -324,11 +447,14 @@ class LevelPosFn(torch.autograd.Function):
         geo, N = ctx.geo, ctx.N
         d_pos = _c(d_pos)
         C = d_pos.shape[-1]
-        d_le = torch.zeros(geo.L, C, dtype=torch.float32, device=d_pos.device)
+        sink = _sink(ctx.le_ref)
+        d_le = sink if sink is not None else torch.zeros(geo.L, C, dtype=torch.float32, device=d_pos.device)
         for l in range(geo.L):
             h, w = geo.shapes[l]
-            for n in range(N):
-                ops.colsum(d_pos[n, geo.starts[l]:], h * w, C, d_le[l])
+            ops.colsum(d_pos[0, geo.starts[l]:], h * w, C, d_le[l], nbatch=N, batch_stride=geo.S * C)
+        if sink is not None:
+            Runtime.notify(_param_of(ctx.le_ref))
+            d_le = None
         return (None, d_le) + (None,) * geo.L
 
 
@@ -384,6 +510,7 @@ class MHAFn(torch.autograd.Function):
         out = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
         ops.gemm(O.view(-1, C), out_w, out, N * Lq, C, C, bias=out_b)
         ctx.save_for_backward(q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm_u8)
+        ctx.refs = (in_w, in_b, out_w, out_b)
         ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in)
         return out
 
@@ -398,21 +525,41 @@ class MHAFn(torch.autograd.Function):
         Mq, Mk = N * Lq, N * Lk
         dO = torch.empty(Mq, C, dtype=torch.float32, device=dev)
         ops.gemm(d_out2, out_w, dO, Mq, C, C, a_mode=0, b_mode=1)
-        d_out_w = torch.zeros(C, C, dtype=torch.float32, device=dev)
-        ops.gemm(d_out2, O.view(-1, C), d_out_w, C, C, Mq, a_mode=1, b_mode=1, accumulate=True,
-                 split_k=ops.pick_split_k(C, C, Mq))
-        d_out_b = torch.zeros(C, dtype=torch.float32, device=dev)
-        ops.colsum(d_out2, Mq, C, d_out_b)
+        sinks = [_sink(t) for t in ctx.refs]
+        direct = all(k is not None for k in sinks)
+        d_out_w = sinks[2] if direct else torch.zeros(C, C, dtype=torch.float32, device=dev)
+        d_out_b = sinks[3] if direct else torch.zeros(C, dtype=torch.float32, device=dev)
+        d_in_w = sinks[0] if direct else torch.zeros(3 * C, C, dtype=torch.float32, device=dev)
+        d_in_b = sinks[1] if direct else torch.zeros(3 * C, dtype=torch.float32, device=dev)
+
+        def out_grads():
+            ops.gemm(d_out2, O.view(-1, C), d_out_w, C, C, Mq, a_mode=1, b_mode=1, accumulate=True,
+                     split_k=ops.pick_split_k(C, C, Mq))
+            ops.colsum(d_out2, Mq, C, d_out_b)
+
+        if direct:
+            with _Side(d_out2, O):
+                out_grads()
+        else:
+            out_grads()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         rng = Runtime.get_rng(dev) if p > 0 else None
         ops.attn_bwd(dO.view(N, Lq, C), q, k, v, O, lse, dq, dk, dv, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm,
                      dropout_p=p, rng=rng, rng_stream=stream)
-        d_in_w = torch.zeros(3 * C, C, dtype=torch.float32, device=dev)
-        d_in_b = torch.zeros(3 * C, dtype=torch.float32, device=dev)
-        for i, (g, src, M) in enumerate(((dq, q_in, Mq), (dk, k_in, Mk), (dv, v_in, Mk))):
-            ops.gemm(g.view(-1, C), src.view(-1, C), d_in_w[i * C:], C, C, M, a_mode=1, b_mode=1, accumulate=True,
-                     split_k=ops.pick_split_k(C, C, M))
-            ops.colsum(g.view(-1, C), M, C, d_in_b[i * C:])
+
+        def in_grads():
+            for i, (g, src, M) in enumerate(((dq, q_in, Mq), (dk, k_in, Mk), (dv, v_in, Mk))):
+                ops.gemm(g.view(-1, C), src.view(-1, C), d_in_w[i * C:], C, C, M, a_mode=1, b_mode=1, accumulate=True,
+                         split_k=ops.pick_split_k(C, C, M))
+                ops.colsum(g.view(-1, C), M, C, d_in_b[i * C:])
+
+        if direct:
+            with _Side(dq, dk, dv, q_in, k_in, v_in):
+                in_grads()
+            Runtime.notify(*[_param_of(t) for t in ctx.refs])
+            d_in_w = d_in_b = d_out_w = d_out_b = None
+        else:
+            in_grads()
         dq_in = dk_in = dv_in = None
         if ctx.needs_input_grad[0]:
             dq_in = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
@@ -441,6 +588,7 @@ class TokenEmbedFn(torch.autograd.Function):
         deltas = [_c(d).view(-1) for d in (dx1, dx2, dy1, dy2)]
         out = ops.token_embed_fwd(table, seqs, deltas)
         ctx.save_for_backward(*seqs, *deltas)
+        ctx.t_ref = table
         ctx.meta = (table.shape, pad_idx)
         return out.view(*shape, table.shape[1])
 
@@ -448,8 +596,12 @@ class TokenEmbedFn(torch.autograd.Function):
     def backward(ctx, d_out):
         sv = ctx.saved_tensors
         tshape, pad_idx = ctx.meta
-        d_table = torch.zeros(tshape, dtype=torch.float32, device=d_out.device)
+        sink = _sink(ctx.t_ref)
+        d_table = sink if sink is not None else torch.zeros(tshape, dtype=torch.float32, device=d_out.device)
         ops.token_embed_bwd(_c(d_out).view(-1, tshape[1]), sv[:4], sv[4:], d_table, pad_idx if pad_idx is not None else -1)
+        if sink is not None:
+            Runtime.notify(_param_of(ctx.t_ref))
+            d_table = None
         return (d_table,) + (None,) * 9
 
 
@@ -546,6 +698,7 @@ class SupportEmbedFn(torch.autograd.Function):
         C = W0.shape[0]
         h, pe = ops.support_embed_fwd(coords, W0, b0, pe1d, N, P, C)
         ctx.save_for_backward(h, coords)
+        ctx.refs = (W0, b0)
         ctx.meta = (N, P, C)
         ctx.mark_non_differentiable(pe)
         return h.view(N, P, C), pe.view(N, P, C)
@@ -554,9 +707,14 @@ class SupportEmbedFn(torch.autograd.Function):
     def backward(ctx, d_h, _d_pe):
         h, coords = ctx.saved_tensors
         N, P, C = ctx.meta
-        dW = torch.zeros(C, 2, dtype=torch.float32, device=h.device)
-        db = torch.zeros(C, dtype=torch.float32, device=h.device)
+        ws, bs = _sink(ctx.refs[0]), _sink(ctx.refs[1])
+        direct = ws is not None and bs is not None
+        dW = ws if direct else torch.zeros(C, 2, dtype=torch.float32, device=h.device)
+        db = bs if direct else torch.zeros(C, dtype=torch.float32, device=h.device)
         ops.support_embed_bwd(_c(d_h).view(-1, C), h, coords, dW, db, N, P, C)
+        if direct:
+            Runtime.notify(_param_of(ctx.refs[0]), _param_of(ctx.refs[1]))
+            dW = db = None
         return None, dW, db, None
 
 

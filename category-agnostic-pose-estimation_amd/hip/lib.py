@@ -40,7 +40,7 @@ P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
 _SIGS = {
     "cape_rng_advance": [P, P],
     "cape_gemm_f32": [POINTER(GemmDesc), P],
-    "cape_colsum_f32": [P, LL, I, I, P, I, P],
+    "cape_colsum_f32": [P, LL, I, LL, I, I, P, I, P],
     "cape_add_layernorm_fwd": [P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
     "cape_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
     "cape_groupnorm_fwd": [P, P, P, P, LL, P, P, I, I, I, I, P],

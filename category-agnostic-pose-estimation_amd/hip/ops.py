@@ -89,7 +89,11 @@ class GemmProfiler:
         torch.cuda.synchronize()
         flops = sum(r[2] for r in cls.records)
         ms = sum(r[0].elapsed_time(r[1]) for r in cls.records)
-        return {"launches": len(cls.records), "flops": flops, "ms": ms}
+        table = {}
+        for r in cls.records:
+            t = table.setdefault(r[3], [0, 0.0, 0.0])
+            t[0] += 1; t[1] += r[0].elapsed_time(r[1]); t[2] += r[2]
+        return {"launches": len(cls.records), "flops": flops, "ms": ms, "table": table}
 
 
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
@@ -134,18 +138,18 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         e0.record()
         lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
         e1.record()
-        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K))
+        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K, (M, N, K, a_mode, b_mode, int(split_k))))
         return
     lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
 
 
-def colsum(X, M, N, out, ldx=None, accumulate=True):
+def colsum(X, M, N, out, ldx=None, accumulate=True, nbatch=1, batch_stride=0):
     _chk(X, "colsum.X", contiguous=False)
-    _chk(out, "colsum.out")
+    _chk(out, "colsum.out", contiguous=False)
     ldx = N if ldx is None else ldx
-    assert M == 0 or _avail(X) >= (M - 1) * ldx + N
+    assert M == 0 or _avail(X) >= (nbatch - 1) * batch_stride + (M - 1) * ldx + N
     assert _avail(out) >= N
-    lib.call("cape_colsum_f32", _p(X), ldx, M, N, _p(out), int(accumulate), _stream())
+    lib.call("cape_colsum_f32", _p(X), ldx, nbatch, batch_stride, M, N, _p(out), int(accumulate), _stream())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -235,9 +239,9 @@ def msda_fwd(value, offw, ref, geo, N, Lq, P=4):
 
 def msda_bwd(d_out, value, offw, ref, geo, N, Lq, P=4, need_ref_grad=True):
     _chk(d_out, "msda_bwd.d_out")
-    d_value = torch.zeros_like(value)
+    d_value = torch.empty_like(value)
     d_offw = torch.empty_like(offw)
-    d_ref = torch.zeros_like(ref) if need_ref_grad else None
+    d_ref = torch.empty_like(ref) if need_ref_grad else None
     lib.call("cape_msda_bwd", _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
              _p(d_offw), _p(d_ref), N, geo.S, Lq, geo.L, P, _stream())
     return d_value, d_offw, d_ref

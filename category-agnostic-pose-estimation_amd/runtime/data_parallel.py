@@ -19,6 +19,8 @@ import contextlib
 import torch
 import torch.distributed as dist
 
+from ..hip import functional as HF
+
 
 class EpisodeDataParallel:
     def __init__(self, model, optimizer, bucket_mb=25.0, process_group=None):
@@ -62,16 +64,35 @@ class EpisodeDataParallel:
                 p = a.params[i]
                 self._bucket_of[id(p)] = bi
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
+        # parameters whose wgrad kernels write the arena directly (no autograd accumulation) report here
+        HF.Runtime.on_param_grad.append(self._on_direct_grad)
         self._reset_pending()
+
+    def _on_direct_grad(self, p):
+        bi = self._bucket_of.get(id(p))
+        if bi is None or not self.sync_enabled:
+            return
+        key = (bi, id(p))
+        if key in self._seen:
+            return                                  # a parameter used twice in one backward counts once
+        self._seen.add(key)
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
 
     def _reset_pending(self):
         self._pending = {bi: len(b[3]) for bi, b in enumerate(self.buckets)}
         self._launched = set()
+        self._seen = set()
 
     def _make_hook(self, bi):
         def hook(_p):
             if not self.sync_enabled:
                 return
+            key = (bi, id(_p))
+            if key in self._seen:
+                return
+            self._seen.add(key)
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -84,6 +105,8 @@ class EpisodeDataParallel:
         a, lo, hi, _ = self.buckets[bi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if HF.Runtime.side is not None:
+                self.comm_stream.wait_stream(HF.Runtime.side)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(a.grad[lo:hi], group=self.pg)
         else:

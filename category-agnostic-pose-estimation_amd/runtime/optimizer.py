@@ -5,6 +5,7 @@
 `step`, `zero_grad`, `state_dict`/`load_state_dict` in torch's per-parameter format so checkpoints interchange."""
 import torch
 
+from ..hip import functional as HF
 from ..hip import ops
 from .arena import ParamGroupArena, split_groups
 
@@ -20,9 +21,12 @@ class ArenaAdamW(torch.optim.Optimizer):
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        # weight-gradient kernels may now accumulate straight into the gradient arenas (hip/functional.py)
+        HF.Runtime.direct_grad = device.type == "cuda"
 
     @torch.no_grad()
     def step(self, closure=None):
+        HF.Runtime.join()                       # side-stream wgrad kernels must have landed in the arenas
         self.sumsq.zero_()
         if self.max_norm > 0:
             for a in self.arenas:

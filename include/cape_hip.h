@@ -76,8 +76,10 @@ typedef struct {
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
 
-/* column sums:  out[n] (+)= sum_m X[m][n]   (bias gradients; level_embed gradient) */
-int cape_colsum_f32(const float* X, long long ldx, int M, int N, float* out, int accumulate, cape_stream_t stream);
+/* column sums over nbatch row blocks:  out[n] (+)= sum_b sum_m X[b*batch_stride + m*ldx + n]
+ * (bias gradients: nbatch = 1; level_embed gradient: one block of a level's rows per image) */
+int cape_colsum_f32(const float* X, long long ldx, int nbatch, long long batch_stride, int M, int N, float* out,
+                    int accumulate, cape_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out = LayerNorm(x + dropout(y)) * gamma + beta over rows of C (C <= 1024, C % 4 == 0), eps 1e-5.
@@ -126,8 +128,7 @@ int cape_groupnorm_bwd(const float* d_out, long long d_out_image_stride, const f
 int cape_msda_fwd(const float* value, const float* offw, const float* ref, const int* shapes,
                   const int* level_start, float* out, int N, int S, int Lq, int L, int P,
                   cape_stream_t stream);
-/* backward: d_value must be zero-initialised by the caller (atomically accumulated); d_offw, d_ref written
- * (d_ref may be NULL). */
+/* backward: d_value, d_offw and d_ref (may be NULL) are fully written (no caller-side zero fill needed). */
 int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
                   const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
                   int N, int S, int Lq, int L, int P, cape_stream_t stream);

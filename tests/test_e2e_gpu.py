@@ -145,3 +145,52 @@ def test_train_mode_step_runs_and_is_finite(proc_sd):
     for n, p in model.named_parameters():
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), n
+
+
+def test_arena_direct_grads_and_optimizer_step(golden_dir, proc_sd):
+    """Training path as deployed: flat arenas, wgrad kernels accumulating straight into the gradient arena on
+    the side stream, fused clip + AdamW.  Gradients against the reference goldens; the update against
+    torch.optim.AdamW + clip_grad_norm_ fed with the same gradients on the CPU."""
+    import cape_amd  # noqa: F401
+    from cape_amd.runtime.optimizer import ArenaAdamW
+    d = np.load(os.path.join(golden_dir, "e2e64.npz"))
+    args, tok, model, crit = build_product(proc_sd=proc_sd)
+    model.eval()                                           # dropout off -> comparable with the goldens
+    opt = ArenaAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, max_norm=0.1)
+    names = {id(p): n for n, p in model.named_parameters()}
+    b = to_dev(synth.make_batch(11, 2, 2, 64, 9, CFG, n_invisible=(2, 0)))
+    for rep in range(2):                                   # second pass checks zero_grad + re-accumulation
+        opt.zero_grad()
+        out = model(samples=b["images"], support_coords=b["support_coords"], support_mask=b["support_mask"],
+                    targets=b["targets"], skeleton_edges=b["skeleton"])
+        crit(out, b["targets"])["_total"].backward()
+        torch.cuda.synchronize()
+        named = dict(model.named_parameters(remove_duplicate=False))
+        gk = json.loads(bytes(d["gnorm_keys"]).decode())
+        worst = 0.0
+        for name, ref in zip(gk, d["gnorm_vals"]):
+            worst = max(worst, abs(float(named[name].grad.norm()) - ref) / max(ref, 1e-3))
+        assert worst < 2e-2, (rep, worst)
+        for k in d.files:
+            if k.startswith("grad:"):
+                ref = t(d[k])
+                got = named[k[5:]].grad.detach().cpu()
+                assert (got - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max())), (rep, k)
+    # optimizer step vs torch
+    cpu_params, cpu_groups = [], [[], []]
+    for gi, a in enumerate(opt.arenas):
+        for p in a.params:
+            q = torch.nn.Parameter(p.detach().cpu().clone())
+            q.grad = p.grad.detach().cpu().clone()
+            cpu_groups[gi].append(q)
+    ref_opt = torch.optim.AdamW([{"params": cpu_groups[0]}, {"params": cpu_groups[1], "lr": 1e-5}], lr=1e-4, weight_decay=1e-4)
+    total_norm = torch.nn.utils.clip_grad_norm_(cpu_groups[0] + cpu_groups[1], 0.1)
+    ref_opt.step()
+    opt.step()
+    torch.cuda.synchronize()
+    assert abs(float(opt.grad_norm()) - float(total_norm)) <= 1e-3 * float(total_norm)
+    for gi, a in enumerate(opt.arenas):
+        for p, q in zip(a.params, cpu_groups[gi]):
+            assert (p.detach().cpu() - q.detach()).abs().max() <= 1e-6, names[id(p)]
+    for n, p in opt.dead:                                   # never-grad parameters are untouched
+        assert torch.equal(p.detach().cpu(), proc_sd[n])
