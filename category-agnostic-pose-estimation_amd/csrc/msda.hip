@@ -9,6 +9,7 @@
 // Backward: one wave per (query, head pair): lane = half*32 + channel so that every atomic
 // wave-instruction on d_value is two full 128-byte segments (the shape the memory-side float atomics
 // run at full rate for, MI355X_MICROARCH.md "Global float atomics").
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -212,11 +213,12 @@ __global__ void __launch_bounds__(256) msda_bwd_kernel(const float* __restrict__
 // backward, LDS-accumulating form.  One block per (image, head, level group): the d_value slab of that
 // (image, head) for the group's levels lives in LDS (level 0: H0*W0*128 B; remaining levels together),
 // every tap is an LDS atomic (ds_add_f32) instead of a memory-side atomic, and the slab is written back
-// with plain stores (exclusive owner -> d_value needs no zero fill).  8 query slots x 32 channels per block.
+// with plain stores (exclusive owner -> d_value needs no zero fill).  32 query slots x 32 channels per block
+// (16 waves: the loop is a chain of dependent L2 gathers, so memory-level parallelism per CU is what counts).
 // d_aw is emitted raw (gradient w.r.t. the softmaxed weight); msda_softmax_bwd_kernel turns it into the
 // logit gradient afterwards (the softmax spans samples handled by both groups).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) msda_bwd_lds_kernel(const float* __restrict__ d_out, const float* __restrict__ value,
+__global__ void __launch_bounds__(1024) msda_bwd_lds_kernel(const float* __restrict__ d_out, const float* __restrict__ value,
                                                             const float* __restrict__ offw, const float* __restrict__ ref,
                                                             float* __restrict__ d_value, float* __restrict__ d_offw,
                                                             float* __restrict__ d_ref, Levels lv, int N, int S, int Lq, int L,
@@ -226,19 +228,19 @@ __global__ void __launch_bounds__(256) msda_bwd_lds_kernel(const float* __restri
   const int pix0 = sel4(lv.start, lvl_begin);
   const int pix1 = (lvl_end < L) ? sel4(lv.start, lvl_end) : S;
   const int npix = pix1 - pix0;
-  for (int i = threadIdx.x; i < npix * HD; i += 256) dval[i] = 0.f;
+  for (int i = threadIdx.x; i < npix * HD; i += 1024) dval[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int c = lane & 31;
-  const int slot = threadIdx.x >> 5;                               // 8 query slots
+  const int slot = threadIdx.x >> 5;                               // 32 query slots
   const int LP = L * P;
   const int j = c & 15;
   const int rowlen = HEADS * LP * 3;
   const float* vbase = value + (long long)n * S * CH + h * HD + c;
   const int jb = lvl_begin * P, je = lvl_end * P;                  // this group's sample range
-  const int iters = (Lq + 7) >> 3;
+  const int iters = (Lq + 31) >> 5;
   for (int it = 0; it < iters; ++it) {
-    const int q = it * 8 + slot;
+    const int q = it * 32 + slot;
     const bool qlive = q < Lq;                                     // half-wave uniform
     const long long qrow = (long long)n * Lq + (qlive ? q : 0);
     const float* ow = offw + qrow * rowlen;
@@ -262,32 +264,51 @@ __global__ void __launch_bounds__(256) msda_bwd_lds_kernel(const float* __restri
     const float aw = e / sm;
     const float go = qlive ? d_out[qrow * CH + h * HD + c] : 0.f;
     float my_daw = 0.f, my_dpx = 0.f, my_dpy = 0.f;
-    for (int jj = jb; jj < je; ++jj) {
-      const int src = (lane & 32) | jj;
-      const float x = __shfl(px, src, 64), y = __shfl(py, src, 64), a = __shfl(aw, src, 64);
-      const int l = __shfl(l_own, src, 64);
-      const int W = sel4(lv.W, l), H = sel4(lv.H, l);
-      const float xf = floorf(x), yf = floorf(y);
-      const float fx = x - xf, fy = y - yf;
-      const int x0 = (int)xf, y0 = (int)yf;
-      const int lofs = sel4(lv.start, l);
-      const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
-      const bool ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
-      float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
-      const float ga = go * a;
-      if (qlive) {
-        if (ya && xa) { const int p_ = lofs + y0 * W + x0; v00 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * (1.f - fx) * (1.f - fy)); }
-        if (ya && xb) { const int p_ = lofs + y0 * W + x0 + 1; v01 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * fx * (1.f - fy)); }
-        if (yb && xa) { const int p_ = lofs + (y0 + 1) * W + x0; v10 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * (1.f - fx) * fy); }
-        if (yb && xb) { const int p_ = lofs + (y0 + 1) * W + x0 + 1; v11 = vbase[(long long)p_ * CH]; atomicAdd(&dval[(p_ - pix0) * HD + c], ga * fx * fy); }
+    // samples in chunks of 4: all 16 gathers of a chunk are issued before any is consumed (the loop is a chain of
+    // dependent L2 gathers; memory-level parallelism per wave is what bounds it)
+    for (int jc = jb; jc < je; jc += 4) {
+      float v[4][4], fxs[4], fys[4], gas[4];
+      int base[4], Ws[4], bits[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int jj = jc + s_;
+        const int src = (lane & 32) | (jj & 15);
+        const float x = __shfl(px, src, 64), y = __shfl(py, src, 64), a = __shfl(aw, src, 64);
+        const int l = __shfl(l_own, src, 64);
+        const int W = sel4(lv.W, l), H = sel4(lv.H, l);
+        const float xf = floorf(x), yf = floorf(y);
+        fxs[s_] = x - xf; fys[s_] = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const bool ok = qlive && jj < je;
+        const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
+        bits[s_] = ok ? ((ya && xa) | ((ya && xb) << 1) | ((yb && xa) << 2) | ((yb && xb) << 3)) : 0;
+        base[s_] = sel4(lv.start, l) + y0 * W + x0;
+        Ws[s_] = W;
+        gas[s_] = go * a;
+        v[s_][0] = (bits[s_] & 1) ? vbase[(long long)base[s_] * CH] : 0.f;
+        v[s_][1] = (bits[s_] & 2) ? vbase[(long long)(base[s_] + 1) * CH] : 0.f;
+        v[s_][2] = (bits[s_] & 4) ? vbase[(long long)(base[s_] + W) * CH] : 0.f;
+        v[s_][3] = (bits[s_] & 8) ? vbase[(long long)(base[s_] + W + 1) * CH] : 0.f;
       }
-      const float samp = (1.f - fy) * ((1.f - fx) * v00 + fx * v01) + fy * ((1.f - fx) * v10 + fx * v11);
-      const float dsx = (1.f - fy) * (v01 - v00) + fy * (v11 - v10);
-      const float dsy = (1.f - fx) * (v10 - v00) + fx * (v11 - v01);
-      const float r_aw = half_sum32(go * samp);
-      const float r_px = half_sum32(ga * dsx);
-      const float r_py = half_sum32(ga * dsy);
-      if (j == jj) { my_daw = r_aw; my_dpx = r_px; my_dpy = r_py; }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int jj = jc + s_;
+        const float fx = fxs[s_], fy = fys[s_], ga = gas[s_];
+        const int b_ = base[s_] - pix0;
+        if (bits[s_] & 1) atomicAdd(&dval[b_ * HD + c], ga * (1.f - fx) * (1.f - fy));
+        if (bits[s_] & 2) atomicAdd(&dval[(b_ + 1) * HD + c], ga * fx * (1.f - fy));
+        if (bits[s_] & 4) atomicAdd(&dval[(b_ + Ws[s_]) * HD + c], ga * (1.f - fx) * fy);
+        if (bits[s_] & 8) atomicAdd(&dval[(b_ + Ws[s_] + 1) * HD + c], ga * fx * fy);
+        const float v00 = v[s_][0], v01 = v[s_][1], v10 = v[s_][2], v11 = v[s_][3];
+        const float samp = (1.f - fy) * ((1.f - fx) * v00 + fx * v01) + fy * ((1.f - fx) * v10 + fx * v11);
+        const float dsx = (1.f - fy) * (v01 - v00) + fy * (v11 - v10);
+        const float dsy = (1.f - fx) * (v10 - v00) + fx * (v11 - v01);
+        const float r_aw = half_sum32(go * samp);
+        const float r_px = half_sum32(ga * dsx);
+        const float r_py = half_sum32(ga * dsy);
+        if (j == jj && jj < je) { my_daw = r_aw; my_dpx = r_px; my_dpy = r_py; }
+      }
     }
     const bool own = qlive && c < 16 && j >= jb && j < je;
     float* dow = d_offw + qrow * rowlen;
@@ -314,7 +335,7 @@ __global__ void __launch_bounds__(256) msda_bwd_lds_kernel(const float* __restri
   }
   __syncthreads();
   float* dvb = d_value + ((long long)n * S + pix0) * CH + h * HD;
-  for (int i = threadIdx.x; i < npix * 8; i += 256) {
+  for (int i = threadIdx.x; i < npix * 8; i += 1024) {
     const int p_ = i >> 3, c4 = (i & 7) * 4;
     *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c4) = *reinterpret_cast<const float4*>(&dval[p_ * HD + c4]);
   }
@@ -390,7 +411,11 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
   const long long pixA = (long long)lv.H[0] * lv.W[0], pixB = (long long)S - pixA;
   const size_t ldsA = (size_t)pixA * HD * sizeof(float), ldsB = (size_t)pixB * HD * sizeof(float);
   const size_t kMaxLds = 144 * 1024;
-  if (L >= 2 && ldsA <= kMaxLds && ldsB <= kMaxLds && (long long)N * HEADS < (1ll << 31)) {
+  // Measured on MI355X (round 1, N=32, S=Lq=1360): the LDS form is SLOWER than memory-side atomics (2.0 ms vs
+  // 1.7 ms per encoder layer): ds_add_f32 throughput per CU is no better than the chip-wide global float-atomic
+  // rate per CU, and one (image, head) per CU leaves too few waves.  Kept opt-in for further tuning.
+  static const bool use_lds = getenv("CAPE_MSDA_BWD_LDS") != nullptr;
+  if (use_lds && L >= 2 && ldsA <= kMaxLds && ldsB <= kMaxLds && (long long)N * HEADS < (1ll << 31)) {
     static bool attr_done = false;
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_lds_kernel),
@@ -402,9 +427,9 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
       hipError_t e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
       if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(256), ldsA, as_stream(stream), d_out, value, offw,
+    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(1024), ldsA, as_stream(stream), d_out, value, offw,
                        ref, d_value, d_offw, d_ref, lv, N, S, Lq, L, P, 0, 1);
-    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(256), ldsB, as_stream(stream), d_out, value, offw,
+    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(1024), ldsB, as_stream(stream), d_out, value, offw,
                        ref, d_value, d_offw, d_ref, lv, N, S, Lq, L, P, 1, L);
     const long long rows = (long long)N * Lq;
     hipLaunchKernelGGL(msda_softmax_bwd_kernel, dim3((unsigned)((rows * HEADS + 255) / 256)), dim3(256), 0, as_stream(stream),

@@ -4,6 +4,8 @@ Each `torch.autograd.Function` here is glue: forward and backward only *launch* 
 libcape_hip.so (through `ops`) and keep the tensors backward needs.  No arithmetic of the hot path is
 done by torch ops in this file.
 """
+import os
+
 import torch
 
 from . import ops
@@ -18,6 +20,7 @@ class Runtime:
     bucket's all-reduce as soon as its gradients have been enqueued."""
     rng = None
     direct_grad = False
+    use_side_stream = os.environ.get("CAPE_SIDE_STREAM", "1") == "1"
     side = None
     on_param_grad = []
 
@@ -82,6 +85,9 @@ class _Side:
         self.tensors = [t for t in tensors if t is not None]
 
     def __enter__(self):
+        self.on = Runtime.use_side_stream
+        if not self.on:
+            return self
         self.s = Runtime.side_stream()
         self.s.wait_stream(torch.cuda.current_stream())
         self.ctx = torch.cuda.stream(self.s)
@@ -89,6 +95,8 @@ class _Side:
         return self
 
     def __exit__(self, *a):
+        if not self.on:
+            return False
         self.ctx.__exit__(*a)
         for t in self.tensors:
             t.record_stream(self.s)

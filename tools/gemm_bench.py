@@ -1,0 +1,41 @@
+"""Isolated timing of the fp32-MFMA GEMM family on the shapes of the CAPE training step (no concurrency)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cape_amd  # noqa: E402,F401
+from cape_amd.hip import ops  # noqa: E402
+
+SHAPES = [  # (M, N, K, a_mode, b_mode, split_k)
+    (43520, 256, 256, 0, 0, 1), (43520, 256, 1024, 0, 0, 1), (43520, 1024, 256, 0, 0, 1), (43520, 256, 256, 0, 1, 1),
+    (43520, 384, 256, 0, 0, 1), (6400, 256, 256, 0, 0, 1), (6400, 1024, 256, 0, 0, 1), (256, 256, 43520, 1, 1, 32),
+    (1024, 256, 43520, 1, 1, 8), (256, 1024, 43520, 1, 1, 8), (256, 256, 6400, 1, 1, 25), (8192, 8192, 1024, 0, 0, 1),
+    (4096, 4096, 4096, 0, 0, 1),
+]
+
+
+def main():
+    dev = "cuda"
+    for (M, N, K, am, bm, sk) in SHAPES:
+        A = torch.randn((M, K) if am == 0 else (K, M), device=dev)
+        B = torch.randn((N, K) if bm == 0 else (K, N), device=dev)
+        C = torch.zeros(M, N, device=dev)
+        kw = dict(a_mode=am, b_mode=bm, split_k=sk, accumulate=sk > 1)
+        for _ in range(3):
+            ops.gemm(A, B, C, M, N, K, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        it = 20
+        e0.record()
+        for _ in range(it):
+            ops.gemm(A, B, C, M, N, K, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / it
+        print(f"M={M:6d} N={N:5d} K={K:6d} am={am} bm={bm} sk={sk:2d}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
