@@ -17,6 +17,22 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// PREC 1 = "bf16x3": every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits)
+// when it is staged into LDS, and each 16-deep k-step is three bf16 MFMAs hi*hi + hi*lo + lo*hi accumulated in fp32
+// (the dropped lo*lo term and the split error are ~2^-16 relative per product; accumulation stays fp32).
+// v_mfma_f32_32x32x16_bf16 issues 16x the flops per cycle of the fp32 MFMA, so the split runs the contraction 16/3
+// faster than exact fp32 at ~fp32 storage traffic.  PREC 0 = exact fp32 MFMA (bitwise an fmaf chain).
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(x, y);
+  lo = pk_bf16(x - __uint_as_float(hi << 16), y - __uint_as_float(hi & 0xFFFF0000u));
+}
 
 namespace {
 
@@ -48,7 +64,7 @@ __device__ __forceinline__ float4 ldg4(const float* p, int valid) {
 
 constexpr int BK = 32;
 
-template <int BM, int BN, int AMODE, int BMODE, bool VEC>
+template <int BM, int BN, int AMODE, int BMODE, bool VEC, int PREC>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   constexpr bool A_KC = (AMODE == 0 || AMODE == 2 || AMODE == 3);
   constexpr bool B_KC = (BMODE == 0);
@@ -63,8 +79,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 
   // two LDS buffers per operand: tile t+1 is written into the other buffer in the middle of tile t's MFMAs
   // (one barrier per k-tile; a single wave per SIMD keeps the matrix pipe fed)
-  __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[2][B_SZ];
+  // PREC 1: per operand and buffer two bf16 planes (hi, lo) laid out [row][k] with an 80-byte row stride
+  // (32 k x 2 B + 16 B pad: conflict-free ds_read_b128 of 8 consecutive k per lane)
+  constexpr int PL_LD = 40;                                    // bf16 elements per row
+  constexpr int A_PL = BM * PL_LD, B_PL = BN * PL_LD;          // elements per plane
+  constexpr int A_WORDS = PREC ? A_PL : A_SZ;                  // 2 planes x A_PL bf16 = A_PL 32-bit words
+  constexpr int B_WORDS = PREC ? B_PL : B_SZ;
+  __shared__ __attribute__((aligned(16))) float As[2][A_WORDS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_WORDS];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -98,6 +120,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   constexpr int A_CH = BM / 4;
   const int a_mc = t % A_CH, a_k0 = t / A_CH;
   constexpr int A_KSTEP = 256 / A_CH;
+  static_assert(PREC == 0 || (BM == 64 && BN == 64), "bf16x3 path is built for the 64x64 tile");
   const int b_kc = t & 7, b_r0 = t >> 3;
   constexpr int B_CH = BN / 4;
   const int b_mc = t % B_CH, b_k0 = t / B_CH;
@@ -158,7 +181,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int mc_ = min(mcol, p.M - 4);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-          const int k = kbase + a_k0 + A_KSTEP * j;
+          const int k = kbase + (PREC ? 2 * a_k0 + j : a_k0 + A_KSTEP * j);
           const bool kin = k < p.K;
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long long)(kin ? k : 0) * p.lda + mc_);
           ra[j] = kin ? v : zero4();
@@ -167,7 +190,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int vm = min(4, max(0, p.M - mcol));
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-          const int k = kbase + a_k0 + A_KSTEP * j;
+          const int k = kbase + (PREC ? 2 * a_k0 + j : a_k0 + A_KSTEP * j);
           ra[j] = (k < p.K && vm) ? ldg4(p.A + (long long)k * p.lda + mcol, vm) : zero4();
         }
       }
@@ -230,7 +253,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int nc_ = min(ncol, p.N - 4);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const int k = kbase + b_k0 + B_KSTEP * j;
+          const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
           const bool kin = k < p.K;
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long long)(kin ? k : 0) * p.ldb + nc_);
           rb[j] = kin ? v : zero4();
@@ -239,7 +262,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int vn = min(4, max(0, p.N - ncol));
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const int k = kbase + b_k0 + B_KSTEP * j;
+          const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
           rb[j] = (k < p.K && vn) ? ldg4(p.B + (long long)k * p.ldb + ncol, vn) : zero4();
         }
       }
@@ -248,7 +271,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       const int taps = p.cKH * p.cKW;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int k = kbase + b_k0 + B_KSTEP * j;
+        const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
         const bool kin = k < p.K;
         const int kq = kin ? k : 0;
         const int tap = kq / p.cO, o = kq - tap * p.cO;
@@ -262,7 +285,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int k = kbase + b_k0 + B_KSTEP * j;
+        const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
         const bool kin = k < p.K;
         const int kq = kin ? k : 0;
         const int ox = kq % p.cOW;
@@ -279,25 +302,76 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   };
 
   auto store_tiles = [&](int buf) {
-    float* Ad = As[buf];
-    float* Bd = Bs[buf];
-    if constexpr (A_KC) {
+    if constexpr (PREC == 0) {
+      float* Ad = As[buf];
+      float* Bd = Bs[buf];
+      if constexpr (A_KC) {
 #pragma unroll
-      for (int j = 0; j < NA; ++j)
-        *reinterpret_cast<float4*>(&Ad[(a_r0 + 32 * j) * A_LD + 4 * a_kc]) = ra[j];
+        for (int j = 0; j < NA; ++j)
+          *reinterpret_cast<float4*>(&Ad[(a_r0 + 32 * j) * A_LD + 4 * a_kc]) = ra[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+          *reinterpret_cast<float4*>(&Ad[(a_k0 + A_KSTEP * j) * A_LD + 4 * a_mc]) = ra[j];
+      }
+      if constexpr (B_KC) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          *reinterpret_cast<float4*>(&Bd[(b_r0 + 32 * j) * B_LD + 4 * b_kc]) = rb[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          *reinterpret_cast<float4*>(&Bd[(b_k0 + B_KSTEP * j) * B_LD + 4 * b_mc]) = rb[j];
+      }
     } else {
+      unsigned short* Ah = reinterpret_cast<unsigned short*>(As[buf]);
+      unsigned short* Al = Ah + A_PL;
+      unsigned short* Bh = reinterpret_cast<unsigned short*>(Bs[buf]);
+      unsigned short* Bl = Bh + B_PL;
+      if constexpr (A_KC) {          // 4 consecutive k of one row -> one 8-byte store per plane
 #pragma unroll
-      for (int j = 0; j < NA; ++j)
-        *reinterpret_cast<float4*>(&Ad[(a_k0 + A_KSTEP * j) * A_LD + 4 * a_mc]) = ra[j];
-    }
-    if constexpr (B_KC) {
+        for (int j = 0; j < NA; ++j) {
+          unsigned h0, l0, h1, l1;
+          split2(ra[j].x, ra[j].y, h0, l0);
+          split2(ra[j].z, ra[j].w, h1, l1);
+          const int o = (a_r0 + 32 * j) * PL_LD + 4 * a_kc;
+          *reinterpret_cast<uint2*>(Ah + o) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(Al + o) = make_uint2(l0, l1);
+        }
+      } else {                       // rows k, k+1 of 4 consecutive m -> a (k, k+1) pair per m, 4-byte stores
+        const float a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w};
+        const float a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-        *reinterpret_cast<float4*>(&Bd[(b_r0 + 32 * j) * B_LD + 4 * b_kc]) = rb[j];
-    } else {
+        for (int i = 0; i < 4; ++i) {
+          unsigned h, l;
+          split2(a0[i], a1[i], h, l);
+          const int o = (4 * a_mc + i) * PL_LD + 2 * a_k0;
+          *reinterpret_cast<unsigned*>(Ah + o) = h;
+          *reinterpret_cast<unsigned*>(Al + o) = l;
+        }
+      }
+      if constexpr (B_KC) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-        *reinterpret_cast<float4*>(&Bd[(b_k0 + B_KSTEP * j) * B_LD + 4 * b_mc]) = rb[j];
+        for (int j = 0; j < NB; ++j) {
+          unsigned h0, l0, h1, l1;
+          split2(rb[j].x, rb[j].y, h0, l0);
+          split2(rb[j].z, rb[j].w, h1, l1);
+          const int o = (b_r0 + 32 * j) * PL_LD + 4 * b_kc;
+          *reinterpret_cast<uint2*>(Bh + o) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(Bl + o) = make_uint2(l0, l1);
+        }
+      } else {
+        const float b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w};
+        const float b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned h, l;
+          split2(b0[i], b1[i], h, l);
+          const int o = (4 * b_mc + i) * PL_LD + 2 * b_k0;
+          *reinterpret_cast<unsigned*>(Bh + o) = h;
+          *reinterpret_cast<unsigned*>(Bl + o) = l;
+        }
+      }
     }
   };
 
@@ -312,6 +386,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   const int l31 = lane & 31, lh = lane >> 5;
 
   auto compute_groups = [&](int buf, int g0, int g1) {
+    if constexpr (PREC == 1) {
+      // groups 0,1 <-> k-step 0 ; groups 2,3 <-> k-step 1 (two 16-deep bf16 steps per 32-k tile)
+      const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As[buf]);
+      const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs[buf]);
+      const int ks = g0 >> 1;
+      const int ao = (wm * WTM + l31) * PL_LD + ks * 16 + 8 * lh;
+      const int bo = (wn * WTN + l31) * PL_LD + ks * 16 + 8 * lh;
+      const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(Ah + ao);
+      const bf16x8 alo = *reinterpret_cast<const bf16x8*>(Ah + A_PL + ao);
+      const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(Bh + bo);
+      const bf16x8 blo = *reinterpret_cast<const bf16x8*>(Bh + B_PL + bo);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[0][0], 0, 0, 0);
+      return;
+    }
     const float* Ar = As[buf];
     const float* Br = Bs[buf];
 #pragma unroll
@@ -397,11 +487,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 }
 
 template <int BM, int BN>
-int launch_mode(const GemmP& p, int a_mode, int b_mode, bool vec, dim3 grid, hipStream_t s) {
+int launch_mode(const GemmP& p, int a_mode, int b_mode, bool vec, int prec, dim3 grid, hipStream_t s) {
 #define CASE(AM, BM_)                                                                      \
   if (a_mode == AM && b_mode == BM_) {                                                     \
-    if (vec) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true>), grid, dim3(256), 0, s, p);   \
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, false>), grid, dim3(256), 0, s, p);      \
+    if constexpr (BM == 64) {                                                              \
+      if (vec && prec == 1) {                                                              \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 1>), grid, dim3(256), 0, s, p);     \
+        return 0;                                                                          \
+      }                                                                                    \
+    }                                                                                      \
+    if (vec) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 0>), grid, dim3(256), 0, s, p);   \
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, false, 0>), grid, dim3(256), 0, s, p);      \
     return 0;                                                                              \
   }
   CASE(0, 0) CASE(2, 0) CASE(0, 1) CASE(3, 2) CASE(1, 1) CASE(1, 3)
@@ -467,8 +563,9 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   if (d->b_mode == 1) vec = vec && (d->ldb % 4 == 0) && (d->N % 4 == 0) && d->N >= 4;
   if (d->b_mode == 2 || d->b_mode == 3) vec = vec && (d->N % 4 == 0) && d->N >= 4;
   if ((d->a_mode >= 2 || d->b_mode >= 2) && !vec) return cape_set_error("cape_gemm_f32: conv modes need the aligned vector path");
-  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, grid, as_stream(stream))
-               : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, grid, as_stream(stream));
+  CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
+  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, 0, grid, as_stream(stream))
+               : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream));
   if (rc) return rc;
   CAPE_LAUNCH_CHECK("cape_gemm_f32");
   return 0;

@@ -6,6 +6,7 @@ whole GPU node down), and raises if the library reports an error.  No CPU path e
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -96,6 +97,15 @@ class GemmProfiler:
         return {"launches": len(cls.records), "flops": flops, "ms": ms, "table": table}
 
 
+# GEMM arithmetic: "f32" = exact fp32 MFMA, "bf16x3" = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)
+GEMM_PRECISION = {"f32": 0, "bf16x3": 1}[os.environ.get("CAPE_GEMM_PRECISION", "f32")]
+
+
+def set_gemm_precision(name):
+    global GEMM_PRECISION
+    GEMM_PRECISION = {"f32": 0, "bf16x3": 1}[name]
+
+
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None):
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
@@ -116,6 +126,7 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.dropout_p = float(dropout_p)
     d.rng_state = rng.t.data_ptr() if (rng is not None and dropout_p > 0) else None
     d.rng_stream = rng_stream
+    d.precision = GEMM_PRECISION
     # host-side extent checks (dense modes)
     if a_mode == 0 and M > 0:
         assert _avail(A) >= (M - 1) * d.lda + K, "gemm: A too small"

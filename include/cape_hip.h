@@ -72,6 +72,8 @@ typedef struct {
   float dropout_p;         /* 0 = off */
   const uint64_t* rng_state;
   uint32_t rng_stream;
+  int precision;           /* 0 = exact fp32 MFMA; 1 = bf16x3 split (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32
+                              accumulate, ~2^-16 relative per product); odd/unaligned shapes always use 0 */
 } cape_gemm_desc;
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);

@@ -503,3 +503,27 @@ def test_decode_next_tokens_matches_oracle():
         for i in range(4):
             assert torch.equal(de[i].cpu(), dl[i]), (step, i)
         assert torch.equal(u.cpu().bool(), unf2)
+
+
+@pytest.mark.parametrize("M,N,K,am,bm", [(300, 256, 256, 0, 0), (1000, 256, 1024, 0, 0), (640, 128, 256, 0, 1),
+                                         (256, 384, 3000, 1, 1), (70, 260, 512, 0, 0)])
+def test_gemm_bf16x3_split_accuracy(M, N, K, am, bm):
+    """The bf16x3 mode (3 bf16 MFMAs per product, fp32 accumulate) must stay within ~2^-15 of an fp64 product
+    relative to the magnitude sum(|a||b|); exact fp32 MFMA is ~1e-7 on the same measure."""
+    a = rnd(M, K, seed=1) if am == 0 else rnd(K, M, seed=1)
+    b = rnd(N, K, seed=2) if bm == 0 else rnd(K, N, seed=2)
+    A64 = (a if am == 0 else a.t()).double()
+    B64 = (b.t() if bm == 0 else b).double()
+    ref = A64 @ B64
+    mag = A64.abs() @ B64.abs()
+    out = torch.zeros(M, N, device=DEV)
+    errs = {}
+    try:
+        for name in ("f32", "bf16x3"):
+            ops.set_gemm_precision(name)
+            ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, a_mode=am, b_mode=bm)
+            errs[name] = ((out.cpu().double() - ref).abs() / mag).max().item()
+    finally:
+        ops.set_gemm_precision("f32")
+    assert errs["f32"] < 2e-6, errs
+    assert errs["bf16x3"] < 4e-5, errs
