@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   // (one barrier per k-tile; a single wave per SIMD keeps the matrix pipe fed)
   // PREC 1: per operand and buffer two bf16 planes (hi, lo) laid out [row][k] with an 80-byte row stride
   // (32 k x 2 B + 16 B pad: conflict-free ds_read_b128 of 8 consecutive k per lane)
-  constexpr int PL_LD = 40;                                    // bf16 elements per row
+  constexpr int PL_LD = 40;                                    // bf16 elements per row ([row][k] image)
+  constexpr int PM_LD = 68;                                    // 32-bit words per k-pair row ([k/2][mn] image)
   constexpr int A_PL = BM * PL_LD, B_PL = BN * PL_LD;          // elements per plane
   constexpr int A_WORDS = PREC ? A_PL : A_SZ;                  // 2 planes x A_PL bf16 = A_PL 32-bit words
   constexpr int B_WORDS = PREC ? B_PL : B_SZ;
@@ -93,15 +94,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   const int wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
-  //      run of tile ids so neighbouring tiles (same A rows / same B columns) hit the same L2.
+  // ---- XCD-aware work order.  Blocks b and b+8 share an XCD (and its L2).  The grid is 1-D over
+  //      (k-splits x tiles).  Without split-K each XCD gets a contiguous run of tile ids (neighbouring tiles
+  //      share A rows / B columns).  With split-K all tiles of one k-split read the same k-slab of both operands,
+  //      so a split is pinned to one XCD (split = xcd + 8*i): the slab is fetched from HBM once per XCD instead of
+  //      once per tile (measured: the 256x256x43520 wgrad was fabric-bound, 8x read amplification, before this).
   const int ntiles = p.tilesM * p.tilesN;
-  int tile;
+  int tile, split;
   {
     const int bid = blockIdx.x;
-    const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, loc = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    if (p.split_k > 1 && (p.split_k & 7) == 0) {
+      split = xcd + 8 * (loc / ntiles);
+      tile = loc % ntiles;
+    } else if (p.split_k > 1) {
+      split = bid / ntiles;
+      tile = bid - split * ntiles;
+    } else {
+      const int q = ntiles >> 3, r = ntiles & 7;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+      split = 0;
+    }
   }
   const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -109,7 +122,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   // ---- split-K range
   const int ktiles = (p.K + BK - 1) / BK;
   const int per = (ktiles + p.split_k - 1) / p.split_k;
-  const int kt_begin = blockIdx.y * per;
+  const int kt_begin = split * per;
   const int kt_end = min(ktiles, kt_begin + per);
   if (kt_begin >= kt_end) return;
 
@@ -338,17 +351,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
           *reinterpret_cast<uint2*>(Ah + o) = make_uint2(h0, h1);
           *reinterpret_cast<uint2*>(Al + o) = make_uint2(l0, l1);
         }
-      } else {                       // rows k, k+1 of 4 consecutive m -> a (k, k+1) pair per m, 4-byte stores
-        const float a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w};
-        const float a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned h, l;
-          split2(a0[i], a1[i], h, l);
-          const int o = (4 * a_mc + i) * PL_LD + 2 * a_k0;
-          *reinterpret_cast<unsigned*>(Ah + o) = h;
-          *reinterpret_cast<unsigned*>(Al + o) = l;
-        }
+      } else {                       // rows k, k+1 of 4 consecutive m: "pair-major" plane [k/2][m] of 32-bit (k, k+1)
+                                     // words -> one conflict-free 16-byte store per plane (the [m][k] image would
+                                     // put the 16 lanes of a store on 2 banks)
+        unsigned h[4], l[4];
+        split2(ra[0].x, ra[1].x, h[0], l[0]);
+        split2(ra[0].y, ra[1].y, h[1], l[1]);
+        split2(ra[0].z, ra[1].z, h[2], l[2]);
+        split2(ra[0].w, ra[1].w, h[3], l[3]);
+        unsigned* Ah32 = reinterpret_cast<unsigned*>(Ah);
+        const int o = a_k0 * PM_LD + 4 * a_mc;
+        *reinterpret_cast<uint4*>(Ah32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(Ah32 + A_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
       }
       if constexpr (B_KC) {
 #pragma unroll
@@ -361,16 +375,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
           *reinterpret_cast<uint2*>(Bl + o) = make_uint2(l0, l1);
         }
       } else {
-        const float b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w};
-        const float b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned h, l;
-          split2(b0[i], b1[i], h, l);
-          const int o = (4 * b_mc + i) * PL_LD + 2 * b_k0;
-          *reinterpret_cast<unsigned*>(Bh + o) = h;
-          *reinterpret_cast<unsigned*>(Bl + o) = l;
-        }
+        unsigned h[4], l[4];
+        split2(rb[0].x, rb[1].x, h[0], l[0]);
+        split2(rb[0].y, rb[1].y, h[1], l[1]);
+        split2(rb[0].z, rb[1].z, h[2], l[2]);
+        split2(rb[0].w, rb[1].w, h[3], l[3]);
+        unsigned* Bh32 = reinterpret_cast<unsigned*>(Bh);
+        const int o = b_k0 * PM_LD + 4 * b_mc;
+        *reinterpret_cast<uint4*>(Bh32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(Bh32 + B_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
       }
     }
   };
@@ -391,12 +404,33 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As[buf]);
       const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs[buf]);
       const int ks = g0 >> 1;
-      const int ao = (wm * WTM + l31) * PL_LD + ks * 16 + 8 * lh;
-      const int bo = (wn * WTN + l31) * PL_LD + ks * 16 + 8 * lh;
-      const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(Ah + ao);
-      const bf16x8 alo = *reinterpret_cast<const bf16x8*>(Ah + A_PL + ao);
-      const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(Bh + bo);
-      const bf16x8 blo = *reinterpret_cast<const bf16x8*>(Bh + B_PL + bo);
+      bf16x8 ahi, alo, bhi, blo;
+      if constexpr (A_KC) {
+        const int ao = (wm * WTM + l31) * PL_LD + ks * 16 + 8 * lh;
+        ahi = *reinterpret_cast<const bf16x8*>(Ah + ao);
+        alo = *reinterpret_cast<const bf16x8*>(Ah + A_PL + ao);
+      } else {
+        const unsigned* A32 = reinterpret_cast<const unsigned*>(Ah);
+        const int ao = (ks * 8 + 4 * lh) * PM_LD + wm * WTM + l31;
+        const uint4 h4 = make_uint4(A32[ao], A32[ao + PM_LD], A32[ao + 2 * PM_LD], A32[ao + 3 * PM_LD]);
+        const uint4 l4 = make_uint4(A32[A_PL / 2 + ao], A32[A_PL / 2 + ao + PM_LD], A32[A_PL / 2 + ao + 2 * PM_LD],
+                                    A32[A_PL / 2 + ao + 3 * PM_LD]);
+        ahi = __builtin_bit_cast(bf16x8, h4);
+        alo = __builtin_bit_cast(bf16x8, l4);
+      }
+      if constexpr (B_KC) {
+        const int bo = (wn * WTN + l31) * PL_LD + ks * 16 + 8 * lh;
+        bhi = *reinterpret_cast<const bf16x8*>(Bh + bo);
+        blo = *reinterpret_cast<const bf16x8*>(Bh + B_PL + bo);
+      } else {
+        const unsigned* B32 = reinterpret_cast<const unsigned*>(Bh);
+        const int bo = (ks * 8 + 4 * lh) * PM_LD + wn * WTN + l31;
+        const uint4 h4 = make_uint4(B32[bo], B32[bo + PM_LD], B32[bo + 2 * PM_LD], B32[bo + 3 * PM_LD]);
+        const uint4 l4 = make_uint4(B32[B_PL / 2 + bo], B32[B_PL / 2 + bo + PM_LD], B32[B_PL / 2 + bo + 2 * PM_LD],
+                                    B32[B_PL / 2 + bo + 3 * PM_LD]);
+        bhi = __builtin_bit_cast(bf16x8, h4);
+        blo = __builtin_bit_cast(bf16x8, l4);
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[0][0], 0, 0, 0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[0][0], 0, 0, 0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[0][0], 0, 0, 0);
@@ -553,7 +587,8 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.tilesN = (d->N + BMv - 1) / BMv;
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   CAPE_REQUIRE(ntiles < (1ll << 31), "cape_gemm_f32: too many tiles");
-  dim3 grid((unsigned)ntiles, (unsigned)d->split_k);
+  CAPE_REQUIRE(ntiles * d->split_k < (1ll << 31), "cape_gemm_f32: grid too large");
+  dim3 grid((unsigned)(ntiles * d->split_k));
   // vector path: every 16-byte load must be aligned and stay inside its row
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   bool vec = al16(d->A) && al16(d->B);
@@ -593,6 +628,34 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* X, long long l
   if (w == 0 && col < N) atomicAdd(&out[col], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 
+// 16-byte form (N % 4 == 0, aligned rows): a wave covers 256 columns of a row (1 KB contiguous), the block's 4 waves
+// take 4 rows per step; each lane keeps 4 column sums in registers.
+__global__ void __launch_bounds__(256) colsum_vec_kernel(const float* X, long long ldx, long long batch_stride,
+                                                          int rows_per_batch, long long M, int N, float* out,
+                                                          long long rows_per_block) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 4;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < N)
+    for (long long r = r0 + w; r < r1; r += 4) {
+      const long long b = r / rows_per_batch, rr = r - b * rows_per_batch;
+      const float4 v = *reinterpret_cast<const float4*>(X + b * batch_stride + rr * ldx + col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && col < N) {
+    const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+    atomicAdd(&out[col + 0], a.x + b.x + c.x + d.x);
+    atomicAdd(&out[col + 1], a.y + b.y + c.y + d.y);
+    atomicAdd(&out[col + 2], a.z + b.z + c.z + d.z);
+    atomicAdd(&out[col + 3], a.w + b.w + c.w + d.w);
+  }
+}
+
 extern "C" int cape_colsum_f32(const float* X, long long ldx, int nbatch, long long batch_stride, int M, int N, float* out,
                                int accumulate, cape_stream_t stream) {
   CAPE_REQUIRE(X && out && M >= 0 && N > 0 && nbatch >= 1, "cape_colsum_f32: bad arguments");
@@ -602,14 +665,19 @@ extern "C" int cape_colsum_f32(const float* X, long long ldx, int nbatch, long l
   }
   if (M == 0) return 0;
   const long long rows = (long long)M * nbatch;
-  const int gx = (N + 63) / 64;
+  const bool vec = (N % 4 == 0) && (ldx % 4 == 0) && (batch_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int gx = vec ? (N / 4 + 63) / 64 : (N + 63) / 64;
   long long splits = (rows + 127) / 128;
-  const long long max_splits = (2048 + gx - 1) / gx;
+  const long long max_splits = (1024 + gx - 1) / gx;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const long long rpb = (rows + splits - 1) / splits;
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), X, ldx, batch_stride, M, rows, N,
-                     out, rpb);
+  if (vec)
+    hipLaunchKernelGGL(colsum_vec_kernel, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), X, ldx, batch_stride, M,
+                       rows, N, out, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), X, ldx, batch_stride, M, rows,
+                       N, out, rpb);
   CAPE_LAUNCH_CHECK("cape_colsum_f32");
   return 0;
 }

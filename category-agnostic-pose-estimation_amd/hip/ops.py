@@ -70,8 +70,11 @@ def pick_split_k(M, N, K):
     """Enough tiles to fill 256 CUs about twice; each split keeps >= 8 k-tiles of 32."""
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     ktiles = (K + 31) // 32
-    want = max(1, 512 // max(tiles, 1))
-    return int(max(1, min(want, ktiles // 8 if ktiles >= 16 else 1, 64)))
+    want = max(1, 1024 // max(tiles, 1))
+    sk = int(max(1, min(want, ktiles // 8 if ktiles >= 16 else 1, 64)))
+    if sk >= 8:
+        sk = sk // 8 * 8          # multiples of 8: the kernel pins each k-split to one XCD (slab read once per L2)
+    return sk
 
 
 class GemmProfiler:

@@ -10,8 +10,8 @@ from cape_amd.hip import ops  # noqa: E402
 
 SHAPES = [  # (M, N, K, a_mode, b_mode, split_k)
     (43520, 256, 256, 0, 0, 1), (43520, 256, 1024, 0, 0, 1), (43520, 1024, 256, 0, 0, 1), (43520, 256, 256, 0, 1, 1),
-    (43520, 384, 256, 0, 0, 1), (6400, 256, 256, 0, 0, 1), (6400, 1024, 256, 0, 0, 1), (256, 256, 43520, 1, 1, 32),
-    (1024, 256, 43520, 1, 1, 8), (256, 1024, 43520, 1, 1, 8), (256, 256, 6400, 1, 1, 25), (8192, 8192, 1024, 0, 0, 1),
+    (43520, 384, 256, 0, 0, 1), (6400, 256, 256, 0, 0, 1), (6400, 1024, 256, 0, 0, 1), (256, 256, 43520, 1, 1, 64),
+    (1024, 256, 43520, 1, 1, 16), (256, 1024, 43520, 1, 1, 16), (256, 256, 6400, 1, 1, 24), (8192, 8192, 1024, 0, 0, 1),
     (4096, 4096, 4096, 0, 0, 1),
 ]
 
