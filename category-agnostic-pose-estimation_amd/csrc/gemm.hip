@@ -44,6 +44,7 @@ struct GemmP {
   int cN, cH, cW, cC, cKH, cKW, cStride, cPad, cOH, cOW, cO;
   const float* scale; const float* bias; const float* residual; long long ldr;
   int relu, accumulate, split_k;
+  float* colsum_out;
   uint32_t drop_thresh; float inv_keep;
   const uint64_t* rng_state; uint32_t rng_stream;
   int tilesM, tilesN;
@@ -474,14 +475,44 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
     }
   };
 
+  // optional fused bias gradient (a_mode 0 = dgrad of nn.Linear): colsum_out[k] += sum_m A[m][k] from the A tile in
+  // registers (tn == 0 blocks, rows beyond M masked).  Correct, but NOT used by the training path: with hundreds of
+  // M-tiles all adding into the same K addresses the float atomics serialise per address (measured: the step got 30 %
+  // slower); the standalone colsum kernel with <= 96 fat blocks is faster.
+  const bool do_colsum = (AMODE == 0) && p.colsum_out != nullptr && tn == 0;
+  auto colsum_tile = [&](int kt) {
+    if constexpr (AMODE == 0) {
+      float4 cs = zero4();
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        if (m0 + a_r0 + 32 * j < p.M) { cs.x += ra[j].x; cs.y += ra[j].y; cs.z += ra[j].z; cs.w += ra[j].w; }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+        cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+      }
+      const int k = kt * BK + 4 * a_kc;
+      if (lane < 8 && k < p.K) {          // K % 4 == 0 on the vector path; the scalar path guards per element
+        atomicAdd(p.colsum_out + k, cs.x);
+        if (k + 1 < p.K) atomicAdd(p.colsum_out + k + 1, cs.y);
+        if (k + 2 < p.K) atomicAdd(p.colsum_out + k + 2, cs.z);
+        if (k + 3 < p.K) atomicAdd(p.colsum_out + k + 3, cs.w);
+      }
+    }
+  };
+
   load_tiles(kt_begin);
+  if (do_colsum) colsum_tile(kt_begin);
   store_tiles(0);
   __syncthreads();
   if (kt_begin + 1 < kt_end) load_tiles(kt_begin + 1);
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     compute_groups(cur, 0, 2);
-    if (kt + 1 < kt_end) store_tiles(cur ^ 1);     // tile kt+1 (in registers since the previous barrier)
+    if (kt + 1 < kt_end) {
+      if (do_colsum) colsum_tile(kt + 1);
+      store_tiles(cur ^ 1);                        // tile kt+1 (in registers since the previous barrier)
+    }
     compute_groups(cur, 2, 4);
     __syncthreads();                               // all reads of `cur` and writes of `cur^1` are done
     if (kt + 2 < kt_end) load_tiles(kt + 2);
@@ -569,6 +600,8 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.cStride = d->cStride; p.cPad = d->cPad; p.cOH = d->cOH; p.cOW = d->cOW; p.cO = d->cO;
   p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
   p.relu = d->relu; p.accumulate = d->accumulate; p.split_k = d->split_k;
+  p.colsum_out = d->colsum_out;
+  if (d->colsum_out) CAPE_REQUIRE(d->a_mode == 0, "cape_gemm_f32: colsum_out needs a_mode 0");
   p.drop_thresh = d->dropout_p > 0.f ? cape_drop_threshold(d->dropout_p) : 0u;
   p.inv_keep = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
   p.rng_state = d->rng_state; p.rng_stream = d->rng_stream;
@@ -628,31 +661,48 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* X, long long l
   if (w == 0 && col < N) atomicAdd(&out[col], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 
-// 16-byte form (N % 4 == 0, aligned rows): a wave covers 256 columns of a row (1 KB contiguous), the block's 4 waves
-// take 4 rows per step; each lane keeps 4 column sums in registers.
-__global__ void __launch_bounds__(256) colsum_vec_kernel(const float* X, long long ldx, long long batch_stride,
-                                                          int rows_per_batch, long long M, int N, float* out,
-                                                          long long rows_per_block) {
-  __shared__ float4 part[4][64];
+// 16-byte form (N % 4 == 0, aligned rows): a wave covers 256 columns of a row (1 KB contiguous); a block is 16 waves
+// (16 rows per step, 4 rows in flight per wave).  Few, fat blocks on purpose: the final float atomics of all blocks hit
+// the same N addresses and serialise per address (~50 ns each, measured: 340 blocks -> 17 us of pure contention), so the
+// row range is cut into at most ~96 blocks and each block adds once per column.
+__global__ void __launch_bounds__(1024) colsum_vec_kernel(const float* X, long long ldx, long long batch_stride,
+                                                           int rows_per_batch, long long M, int N, float* out,
+                                                           long long rows_per_block) {
+  __shared__ float4 part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + lane) * 4;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   const long long r1 = min(M, r0 + rows_per_block);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < N)
-    for (long long r = r0 + w; r < r1; r += 4) {
-      const long long b = r / rows_per_batch, rr = r - b * rows_per_batch;
-      const float4 v = *reinterpret_cast<const float4*>(X + b * batch_stride + rr * ldx + col);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  auto rowptr = [&](long long r) {
+    const long long b = r / rows_per_batch, rr = r - b * rows_per_batch;
+    return reinterpret_cast<const float4*>(X + b * batch_stride + rr * ldx + col);
+  };
+  if (col < N) {
+    long long r = r0 + w;
+    for (; r + 48 < r1; r += 64) {
+      const float4 a = *rowptr(r), b = *rowptr(r + 16), c = *rowptr(r + 32), d = *rowptr(r + 48);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+      s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
     }
-  part[w][lane] = s;
+    for (; r < r1; r += 16) {
+      const float4 a = *rowptr(r);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+  }
+  part[w][lane] = make_float4(s0.x + s1.x + s2.x + s3.x, s0.y + s1.y + s2.y + s3.y, s0.z + s1.z + s2.z + s3.z,
+                              s0.w + s1.w + s2.w + s3.w);
   __syncthreads();
   if (w == 0 && col < N) {
-    const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
-    atomicAdd(&out[col + 0], a.x + b.x + c.x + d.x);
-    atomicAdd(&out[col + 1], a.y + b.y + c.y + d.y);
-    atomicAdd(&out[col + 2], a.z + b.z + c.z + d.z);
-    atomicAdd(&out[col + 3], a.w + b.w + c.w + d.w);
+    float4 t = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 u = part[k][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    atomicAdd(&out[col + 0], t.x);
+    atomicAdd(&out[col + 1], t.y);
+    atomicAdd(&out[col + 2], t.z);
+    atomicAdd(&out[col + 3], t.w);
   }
 }
 
@@ -667,13 +717,13 @@ extern "C" int cape_colsum_f32(const float* X, long long ldx, int nbatch, long l
   const long long rows = (long long)M * nbatch;
   const bool vec = (N % 4 == 0) && (ldx % 4 == 0) && (batch_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   const int gx = vec ? (N / 4 + 63) / 64 : (N + 63) / 64;
-  long long splits = (rows + 127) / 128;
-  const long long max_splits = (1024 + gx - 1) / gx;
+  long long splits = vec ? (rows + 255) / 256 : (rows + 127) / 128;
+  const long long max_splits = vec ? (96 + gx - 1) / gx : (1024 + gx - 1) / gx;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const long long rpb = (rows + splits - 1) / splits;
   if (vec)
-    hipLaunchKernelGGL(colsum_vec_kernel, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), X, ldx, batch_stride, M,
+    hipLaunchKernelGGL(colsum_vec_kernel, dim3(gx, (unsigned)splits), dim3(1024), 0, as_stream(stream), X, ldx, batch_stride, M,
                        rows, N, out, rpb);
   else
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), X, ldx, batch_stride, M, rows,

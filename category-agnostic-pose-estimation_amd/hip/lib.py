@@ -32,7 +32,7 @@ class GemmDesc(ctypes.Structure):
         ("cStride", c_int), ("cPad", c_int), ("cOH", c_int), ("cOW", c_int), ("cO", c_int),
         ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_longlong),
         ("relu", c_int), ("accumulate", c_int), ("split_k", c_int), ("dropout_p", c_float),
-        ("rng_state", c_void_p), ("rng_stream", c_uint32), ("precision", c_int),
+        ("rng_state", c_void_p), ("rng_stream", c_uint32), ("colsum_out", c_void_p), ("precision", c_int),
     ]
 
 

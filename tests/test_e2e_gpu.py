@@ -17,6 +17,16 @@ from tests.helpers import build_product, to_dev
 CFG = cape_ref.Cfg()
 
 
+@pytest.fixture(params=["bf16x3", "f32"], autouse=True)
+def gemm_precision(request):
+    """Every end-to-end parity test runs in both GEMM arithmetic modes (default bf16x3 split, exact fp32)."""
+    from cape_amd.hip import ops
+    old = ops.get_gemm_precision()
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision(old)
+
+
 def t(a):
     return torch.from_numpy(np.asarray(a))
 

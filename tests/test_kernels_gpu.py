@@ -518,12 +518,24 @@ def test_gemm_bf16x3_split_accuracy(M, N, K, am, bm):
     mag = A64.abs() @ B64.abs()
     out = torch.zeros(M, N, device=DEV)
     errs = {}
+    old = ops.get_gemm_precision()
     try:
         for name in ("f32", "bf16x3"):
             ops.set_gemm_precision(name)
             ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, a_mode=am, b_mode=bm)
             errs[name] = ((out.cpu().double() - ref).abs() / mag).max().item()
     finally:
-        ops.set_gemm_precision("f32")
+        ops.set_gemm_precision(old)
     assert errs["f32"] < 2e-6, errs
     assert errs["bf16x3"] < 4e-5, errs
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 70), (1000, 256, 1024), (43, 64, 36)])
+def test_gemm_fused_colsum(M, N, K):
+    """dgrad GEMM with the fused bias gradient: colsum_out[k] += sum_m A[m][k]."""
+    dy, w = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    out = torch.empty(M, N, device=DEV)
+    cs = torch.full((K,), 2.0, device=DEV)
+    ops.gemm(dy.to(DEV), w.to(DEV), out, M, N, K, a_mode=0, b_mode=1, colsum_out=cs)
+    close(out, dy @ w, name="nn")
+    close(cs, 2.0 + dy.sum(0), tol=2e-4, name="fused colsum")
