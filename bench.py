@@ -195,10 +195,14 @@ def main():
         # dominant kernel = the fp32-MFMA implicit-GEMM family (csrc/gemm.hip: gemm_kernel<...>): every launch of
         # the next steps is bracketed by HIP events on its own stream; achieved = sum(2MNK) / sum(duration)
         nprof = min(2, a.steps)
+        side = HF.Runtime.use_side_stream
+        HF.Runtime.use_side_stream = False       # serial launches: an event pair then brackets exactly one kernel
+        torch.cuda.synchronize()
         ops.GemmProfiler.start()
         for i in range(nprof):
             step(a.warmup + a.steps + i)
         r = ops.GemmProfiler.stop()
+        HF.Runtime.use_side_stream = side
         if os.environ.get("CAPE_BENCH_GEMM_TABLE"):
             rows = sorted(r["table"].items(), key=lambda kv: -kv[1][1])
             for shape, (cnt, ms, fl) in rows[:40]:
@@ -222,6 +226,22 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # the same step with every GEMM on exact fp32 MFMA (CAPE_GEMM_PRECISION=f32), for reference
+    alt = None
+    if world == 1 and not a.no_roofline and ops.get_gemm_precision() != "f32":
+        ops.set_gemm_precision("f32")
+        for i in range(2):
+            step(i)
+        sync()
+        t1 = time.perf_counter()
+        nalt = max(2, a.steps // 2)
+        for i in range(nalt):
+            step(i)
+        sync()
+        dta = time.perf_counter() - t1
+        ops.set_gemm_precision("bf16x3")
+        alt = {"gemm_precision": "f32 (exact fp32 MFMA)", "value": round(B * nalt / dta, 3), "ms_per_step": round(dta / nalt * 1e3, 3)}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -243,7 +263,7 @@ def main():
             "model_tflops": round(value * gflop_ep / 1e3, 2),
             "model_frac_of_f32_mfma_peak": round(value * gflop_ep / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "gemm_precision": ops.get_gemm_precision(),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "alt_exact_f32": alt,
         }
         print(json.dumps(line))
     if world > 1:

@@ -5,6 +5,13 @@ point that returns nonzero raises RuntimeError with `cape_last_error()`.
 """
 import ctypes
 import os
+
+# torch must be imported (and with it the HIP runtime it bundles) BEFORE libcape_hip.so is loaded: the loader resolves
+# libamdhip64.so.7 by soname, and a process must hold exactly one HIP runtime -- the one torch allocates memory and
+# streams with.  Loading this library first would bind it to /opt/rocm's copy and every kernel launch would then see
+# "no ROCm-capable device" for torch's pointers (observed when a CPU-only test imported this module first).
+import torch  # noqa: F401  (import order is load order)
+
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_uint32, c_uint64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
