@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   // PREC 1: per operand and buffer two bf16 planes (hi, lo) laid out [row][k] with an 80-byte row stride
   // (32 k x 2 B + 16 B pad: conflict-free ds_read_b128 of 8 consecutive k per lane)
   constexpr int PL_LD = 40;                                    // bf16 elements per row ([row][k] image)
-  constexpr int PM_LD = 68;                                    // 32-bit words per k-pair row ([k/2][mn] image)
+  constexpr int PMA_LD = BM + 4, PMB_LD = BN + 4;              // 32-bit words per k-pair row ([k/2][mn] image)
   constexpr int A_PL = BM * PL_LD, B_PL = BN * PL_LD;          // elements per plane
   constexpr int A_WORDS = PREC ? A_PL : A_SZ;                  // 2 planes x A_PL bf16 = A_PL 32-bit words
   constexpr int B_WORDS = PREC ? B_PL : B_SZ;
@@ -130,12 +130,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   // ---- per-thread load coordinates
   // K-contig: chunk column kc = t&7 (k offset 4kc), rows (t>>3) + 32j
   // MN-contig: chunks per k-row CH = B?/4; column mc = t % CH, k-row (t / CH) + (256/CH) j
-  const int a_kc = t & 7, a_r0 = t >> 3;
+  // PREC 1 stores 8 bytes per lane per plane with an 80-byte row stride: a 16-lane store group covers two rows, which
+  // must sit 4 rows apart (4 x 80 B = 16 banks) to be conflict-free, so the 8-lane row groups are dealt 0,4,1,5,2,6,3,7
+  const int rg = t >> 3;
+  const int rperm = PREC ? ((rg & 24) | ((rg & 1) << 2) | ((rg >> 1) & 3)) : rg;
+  const int a_kc = t & 7, a_r0 = rperm;
   constexpr int A_CH = BM / 4;
   const int a_mc = t % A_CH, a_k0 = t / A_CH;
   constexpr int A_KSTEP = 256 / A_CH;
-  static_assert(PREC == 0 || (BM == 64 && BN == 64), "bf16x3 path is built for the 64x64 tile");
-  const int b_kc = t & 7, b_r0 = t >> 3;
+  const int b_kc = t & 7, b_r0 = rperm;
   constexpr int B_CH = BN / 4;
   const int b_mc = t % B_CH, b_k0 = t / B_CH;
   constexpr int B_KSTEP = 256 / B_CH;
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int mc_ = min(mcol, p.M - 4);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-          const int k = kbase + (PREC ? 2 * a_k0 + j : a_k0 + A_KSTEP * j);
+          const int k = kbase + (PREC ? 2 * (a_k0 + A_KSTEP * (j >> 1)) + (j & 1) : a_k0 + A_KSTEP * j);
           const bool kin = k < p.K;
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long long)(kin ? k : 0) * p.lda + mc_);
           ra[j] = kin ? v : zero4();
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int vm = min(4, max(0, p.M - mcol));
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-          const int k = kbase + (PREC ? 2 * a_k0 + j : a_k0 + A_KSTEP * j);
+          const int k = kbase + (PREC ? 2 * (a_k0 + A_KSTEP * (j >> 1)) + (j & 1) : a_k0 + A_KSTEP * j);
           ra[j] = (k < p.K && vm) ? ldg4(p.A + (long long)k * p.lda + mcol, vm) : zero4();
         }
       }
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int nc_ = min(ncol, p.N - 4);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
+          const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
           const bool kin = k < p.K;
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long long)(kin ? k : 0) * p.ldb + nc_);
           rb[j] = kin ? v : zero4();
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const int vn = min(4, max(0, p.N - ncol));
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
+          const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
           rb[j] = (k < p.K && vn) ? ldg4(p.B + (long long)k * p.ldb + ncol, vn) : zero4();
         }
       }
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       const int taps = p.cKH * p.cKW;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
+        const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
         const bool kin = k < p.K;
         const int kq = kin ? k : 0;
         const int tap = kq / p.cO, o = kq - tap * p.cO;
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int k = kbase + (PREC ? 2 * b_k0 + j : b_k0 + B_KSTEP * j);
+        const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
         const bool kin = k < p.K;
         const int kq = kin ? k : 0;
         const int ox = kq % p.cOW;
@@ -355,15 +358,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       } else {                       // rows k, k+1 of 4 consecutive m: "pair-major" plane [k/2][m] of 32-bit (k, k+1)
                                      // words -> one conflict-free 16-byte store per plane (the [m][k] image would
                                      // put the 16 lanes of a store on 2 banks)
-        unsigned h[4], l[4];
-        split2(ra[0].x, ra[1].x, h[0], l[0]);
-        split2(ra[0].y, ra[1].y, h[1], l[1]);
-        split2(ra[0].z, ra[1].z, h[2], l[2]);
-        split2(ra[0].w, ra[1].w, h[3], l[3]);
         unsigned* Ah32 = reinterpret_cast<unsigned*>(Ah);
-        const int o = a_k0 * PM_LD + 4 * a_mc;
-        *reinterpret_cast<uint4*>(Ah32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4*>(Ah32 + A_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
+#pragma unroll
+        for (int jj = 0; jj < NA / 2; ++jj) {
+          unsigned h[4], l[4];
+          split2(ra[2 * jj].x, ra[2 * jj + 1].x, h[0], l[0]);
+          split2(ra[2 * jj].y, ra[2 * jj + 1].y, h[1], l[1]);
+          split2(ra[2 * jj].z, ra[2 * jj + 1].z, h[2], l[2]);
+          split2(ra[2 * jj].w, ra[2 * jj + 1].w, h[3], l[3]);
+          const int o = (a_k0 + A_KSTEP * jj) * PMA_LD + 4 * a_mc;
+          *reinterpret_cast<uint4*>(Ah32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
+          *reinterpret_cast<uint4*>(Ah32 + A_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
       }
       if constexpr (B_KC) {
 #pragma unroll
@@ -376,15 +382,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
           *reinterpret_cast<uint2*>(Bl + o) = make_uint2(l0, l1);
         }
       } else {
-        unsigned h[4], l[4];
-        split2(rb[0].x, rb[1].x, h[0], l[0]);
-        split2(rb[0].y, rb[1].y, h[1], l[1]);
-        split2(rb[0].z, rb[1].z, h[2], l[2]);
-        split2(rb[0].w, rb[1].w, h[3], l[3]);
         unsigned* Bh32 = reinterpret_cast<unsigned*>(Bh);
-        const int o = b_k0 * PM_LD + 4 * b_mc;
-        *reinterpret_cast<uint4*>(Bh32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4*>(Bh32 + B_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
+#pragma unroll
+        for (int jj = 0; jj < NB / 2; ++jj) {
+          unsigned h[4], l[4];
+          split2(rb[2 * jj].x, rb[2 * jj + 1].x, h[0], l[0]);
+          split2(rb[2 * jj].y, rb[2 * jj + 1].y, h[1], l[1]);
+          split2(rb[2 * jj].z, rb[2 * jj + 1].z, h[2], l[2]);
+          split2(rb[2 * jj].w, rb[2 * jj + 1].w, h[3], l[3]);
+          const int o = (b_k0 + B_KSTEP * jj) * PMB_LD + 4 * b_mc;
+          *reinterpret_cast<uint4*>(Bh32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
+          *reinterpret_cast<uint4*>(Bh32 + B_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
       }
     }
   };
@@ -405,36 +414,47 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As[buf]);
       const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs[buf]);
       const int ks = g0 >> 1;
-      bf16x8 ahi, alo, bhi, blo;
-      if constexpr (A_KC) {
-        const int ao = (wm * WTM + l31) * PL_LD + ks * 16 + 8 * lh;
-        ahi = *reinterpret_cast<const bf16x8*>(Ah + ao);
-        alo = *reinterpret_cast<const bf16x8*>(Ah + A_PL + ao);
-      } else {
-        const unsigned* A32 = reinterpret_cast<const unsigned*>(Ah);
-        const int ao = (ks * 8 + 4 * lh) * PM_LD + wm * WTM + l31;
-        const uint4 h4 = make_uint4(A32[ao], A32[ao + PM_LD], A32[ao + 2 * PM_LD], A32[ao + 3 * PM_LD]);
-        const uint4 l4 = make_uint4(A32[A_PL / 2 + ao], A32[A_PL / 2 + ao + PM_LD], A32[A_PL / 2 + ao + 2 * PM_LD],
-                                    A32[A_PL / 2 + ao + 3 * PM_LD]);
-        ahi = __builtin_bit_cast(bf16x8, h4);
-        alo = __builtin_bit_cast(bf16x8, l4);
+      bf16x8 ahi[TI], alo[TI], bhi[TJ], blo[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        if constexpr (A_KC) {
+          const int ao = (wm * WTM + 32 * i + l31) * PL_LD + ks * 16 + 8 * lh;
+          ahi[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
+          alo[i] = *reinterpret_cast<const bf16x8*>(Ah + A_PL + ao);
+        } else {
+          const unsigned* A32 = reinterpret_cast<const unsigned*>(Ah);
+          const int ao = (ks * 8 + 4 * lh) * PMA_LD + wm * WTM + 32 * i + l31;
+          const uint4 h4 = make_uint4(A32[ao], A32[ao + PMA_LD], A32[ao + 2 * PMA_LD], A32[ao + 3 * PMA_LD]);
+          const uint4 l4 = make_uint4(A32[A_PL / 2 + ao], A32[A_PL / 2 + ao + PMA_LD], A32[A_PL / 2 + ao + 2 * PMA_LD],
+                                      A32[A_PL / 2 + ao + 3 * PMA_LD]);
+          ahi[i] = __builtin_bit_cast(bf16x8, h4);
+          alo[i] = __builtin_bit_cast(bf16x8, l4);
+        }
       }
-      if constexpr (B_KC) {
-        const int bo = (wn * WTN + l31) * PL_LD + ks * 16 + 8 * lh;
-        bhi = *reinterpret_cast<const bf16x8*>(Bh + bo);
-        blo = *reinterpret_cast<const bf16x8*>(Bh + B_PL + bo);
-      } else {
-        const unsigned* B32 = reinterpret_cast<const unsigned*>(Bh);
-        const int bo = (ks * 8 + 4 * lh) * PM_LD + wn * WTN + l31;
-        const uint4 h4 = make_uint4(B32[bo], B32[bo + PM_LD], B32[bo + 2 * PM_LD], B32[bo + 3 * PM_LD]);
-        const uint4 l4 = make_uint4(B32[B_PL / 2 + bo], B32[B_PL / 2 + bo + PM_LD], B32[B_PL / 2 + bo + 2 * PM_LD],
-                                    B32[B_PL / 2 + bo + 3 * PM_LD]);
-        bhi = __builtin_bit_cast(bf16x8, h4);
-        blo = __builtin_bit_cast(bf16x8, l4);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        if constexpr (B_KC) {
+          const int bo = (wn * WTN + 32 * j + l31) * PL_LD + ks * 16 + 8 * lh;
+          bhi[j] = *reinterpret_cast<const bf16x8*>(Bh + bo);
+          blo[j] = *reinterpret_cast<const bf16x8*>(Bh + B_PL + bo);
+        } else {
+          const unsigned* B32 = reinterpret_cast<const unsigned*>(Bh);
+          const int bo = (ks * 8 + 4 * lh) * PMB_LD + wn * WTN + 32 * j + l31;
+          const uint4 h4 = make_uint4(B32[bo], B32[bo + PMB_LD], B32[bo + 2 * PMB_LD], B32[bo + 3 * PMB_LD]);
+          const uint4 l4 = make_uint4(B32[B_PL / 2 + bo], B32[B_PL / 2 + bo + PMB_LD], B32[B_PL / 2 + bo + 2 * PMB_LD],
+                                      B32[B_PL / 2 + bo + 3 * PMB_LD]);
+          bhi[j] = __builtin_bit_cast(bf16x8, h4);
+          blo[j] = __builtin_bit_cast(bf16x8, l4);
+        }
       }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[0][0], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+        }
       return;
     }
     const float* Ar = As[buf];
@@ -555,11 +575,9 @@ template <int BM, int BN>
 int launch_mode(const GemmP& p, int a_mode, int b_mode, bool vec, int prec, dim3 grid, hipStream_t s) {
 #define CASE(AM, BM_)                                                                      \
   if (a_mode == AM && b_mode == BM_) {                                                     \
-    if constexpr (BM == 64) {                                                              \
-      if (vec && prec == 1) {                                                              \
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 1>), grid, dim3(256), 0, s, p);     \
-        return 0;                                                                          \
-      }                                                                                    \
+    if (vec && prec == 1) {                                                                \
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 1>), grid, dim3(256), 0, s, p);       \
+      return 0;                                                                            \
     }                                                                                      \
     if (vec) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 0>), grid, dim3(256), 0, s, p);   \
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, false, 0>), grid, dim3(256), 0, s, p);      \
@@ -632,7 +650,7 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   if (d->b_mode == 2 || d->b_mode == 3) vec = vec && (d->N % 4 == 0) && d->N >= 4;
   if ((d->a_mode >= 2 || d->b_mode >= 2) && !vec) return cape_set_error("cape_gemm_f32: conv modes need the aligned vector path");
   CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
-  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, 0, grid, as_stream(stream))
+  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream))
                : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream));
   if (rc) return rc;
   CAPE_LAUNCH_CHECK("cape_gemm_f32");

@@ -209,158 +209,254 @@ __global__ void __launch_bounds__(256) msda_bwd_kernel(const float* __restrict__
 }
 
 
+
 // ---------------------------------------------------------------------------------------------
-// backward, LDS-accumulating form.  One block per (image, head, level group): the d_value slab of that
-// (image, head) for the group's levels lives in LDS (level 0: H0*W0*128 B; remaining levels together),
-// every tap is an LDS atomic (ds_add_f32) instead of a memory-side atomic, and the slab is written back
-// with plain stores (exclusive owner -> d_value needs no zero fill).  32 query slots x 32 channels per block
-// (16 waves: the loop is a chain of dependent L2 gathers, so memory-level parallelism per CU is what counts).
-// d_aw is emitted raw (gradient w.r.t. the softmaxed weight); msda_softmax_bwd_kernel turns it into the
-// logit gradient afterwards (the softmax spans samples handled by both groups).
+// backward, split form (the training path).  The two halves of the backward share nothing but the sampling geometry,
+// so they are separate kernels and neither touches a memory-side atomic:
+//
+//   msda_bwd_offw_kernel   d_offw / d_ref.  Gather-only, one wave per query, the forward's lane layout
+//                          (lane = head*8 + c4, 4 channels per lane, a tap of one head = one 128-byte line).
+//                          Each lane owns two of its head's samples: it computes their geometry once and parks it in
+//                          a wave-private LDS record; the 8 lanes of the head then walk the 16 records, gather the
+//                          corners, and reduce go.samp / go.dsx / go.dsy over the head with three DPP steps.
+//
+//   msda_bwd_value_kernel  d_value.  No gathers at all: d_value[n, pix, h, c] = sum over taps of aw * w_corner * go.
+//                          One block per (image, head, 8-channel group): the slab (S+1) x 8 accumulators lives in LDS
+//                          and is written back with plain stores (no zero fill of d_value needed).  The accumulators
+//                          are fp64 on purpose: measured on MI355X (tools/lab/lds_atomic_bench.hip), a conflict-free
+//                          ds_add_f32 wave-instruction costs ~190 clocks (the lanes are serialised), ds_add_f64 8,
+//                          ds_add_u32 4 -- fp32 LDS atomics made the slab form 2x SLOWER than memory-side atomics,
+//                          fp64 ones make it several times faster (and the sum is rounded to fp32 once, at the end).
+//                          Memory-side float atomics run at ~1.3 TB/s chip-wide, which bounded msda_bwd_kernel at
+//                          1.8 ms per encoder layer (N = 32, S = Lq = 1360).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) msda_bwd_lds_kernel(const float* __restrict__ d_out, const float* __restrict__ value,
-                                                            const float* __restrict__ offw, const float* __restrict__ ref,
-                                                            float* __restrict__ d_value, float* __restrict__ d_offw,
-                                                            float* __restrict__ d_ref, Levels lv, int N, int S, int Lq, int L,
-                                                            int P, int lvl_begin, int lvl_end) {
-  extern __shared__ __attribute__((aligned(16))) float dval[];     // [npix][32]
-  const int n = blockIdx.x >> 3, h = blockIdx.x & 7;
-  const int pix0 = sel4(lv.start, lvl_begin);
-  const int pix1 = (lvl_end < L) ? sel4(lv.start, lvl_end) : S;
-  const int npix = pix1 - pix0;
-  for (int i = threadIdx.x; i < npix * HD; i += 1024) dval[i] = 0.f;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int c = lane & 31;
-  const int slot = threadIdx.x >> 5;                               // 32 query slots
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// butterflies inside a DPP row: quad xor 1 (0xB1), quad xor 2 (0x4E), half-row mirror (0x141), row mirror (0x140)
+__device__ __forceinline__ float sum8(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
+__device__ __forceinline__ float max8(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dpp_f<0x140>(v); return v; }
+__device__ __forceinline__ float max16(float v) { v = max8(v); v = fmaxf(v, dpp_f<0x140>(v)); return v; }
+
+// sampling geometry of one (query, head, sample): corner pixel ids (S = tap outside the level) and fractions
+struct Tap { unsigned i00, i01, i10, i11; float fx, fy; };
+__device__ __forceinline__ Tap make_tap(float px, float py, int W, int H, int start, bool live, int S) {
+  const float xf = floorf(px), yf = floorf(py);
+  Tap t;
+  t.fx = px - xf; t.fy = py - yf;
+  const int x0 = (int)xf, y0 = (int)yf;
+  const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
+  const int base = start + y0 * W + x0;
+  t.i00 = (live && ya && xa) ? (unsigned)base : (unsigned)S;
+  t.i01 = (live && ya && xb) ? (unsigned)(base + 1) : (unsigned)S;
+  t.i10 = (live && yb && xa) ? (unsigned)(base + W) : (unsigned)S;
+  t.i11 = (live && yb && xb) ? (unsigned)(base + W + 1) : (unsigned)S;
+  return t;
+}
+
+__global__ void __launch_bounds__(256) msda_bwd_offw_kernel(const float* __restrict__ d_out, const float* __restrict__ value,
+                                                             const float* __restrict__ offw, const float* __restrict__ ref,
+                                                             float* __restrict__ d_offw, float* __restrict__ d_ref, Levels lv,
+                                                             int N, int S, int Lq, int L, int P, int blocks_per_image) {
+  __shared__ uint4 recs[4][HEADS * 16];                          // per wave: [head][sample] {i00|i01<<16, i10|i11<<16, fx, fy}
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int n, chunk;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, loc = b >> 3;                         // blocks sharing b&7 share an XCD: one image, one L2
+    const int ii = loc / blocks_per_image;
+    chunk = loc - ii * blocks_per_image;
+    n = ii * 8 + xcd;
+    if (n >= N) return;
+  }
+  const int q = chunk * 4 + wv;
+  if (q >= Lq) return;                                           // wave-uniform: EXEC stays full for the DPP butterflies
   const int LP = L * P;
-  const int j = c & 15;
+  const int h = lane >> 3, i = lane & 7;
+  const long long qrow = (long long)n * Lq + q;
   const int rowlen = HEADS * LP * 3;
-  const float* vbase = value + (long long)n * S * CH + h * HD + c;
-  const int jb = lvl_begin * P, je = lvl_end * P;                  // this group's sample range
-  const int iters = (Lq + 31) >> 5;
-  for (int it = 0; it < iters; ++it) {
-    const int q = it * 32 + slot;
-    const bool qlive = q < Lq;                                     // half-wave uniform
-    const long long qrow = (long long)n * Lq + (qlive ? q : 0);
-    const float* ow = offw + qrow * rowlen;
-    float px = 0.f, py = 0.f, lg = -INFINITY;
-    int l_own = 0;
-    if (j < LP) {
-      l_own = j / P;
-      const float rx = ref[(qrow * L + l_own) * 2 + 0], ry = ref[(qrow * L + l_own) * 2 + 1];
-      const float ox = ow[(h * LP + j) * 2 + 0], oy = ow[(h * LP + j) * 2 + 1];
-      const float Wf = (float)sel4(lv.W, l_own), Hf = (float)sel4(lv.H, l_own);
-      px = (rx + ox / Wf) * Wf - 0.5f;
-      py = (ry + oy / Hf) * Hf - 0.5f;
-      lg = ow[HEADS * LP * 2 + h * LP + j];
-    }
-    float mx = lg;
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-    const float e = __expf(lg - mx);
-    float sm = e;
-    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
-    const float aw = e / sm;
-    const float go = qlive ? d_out[qrow * CH + h * HD + c] : 0.f;
-    float my_daw = 0.f, my_dpx = 0.f, my_dpy = 0.f;
-    // samples in chunks of 4: all 16 gathers of a chunk are issued before any is consumed (the loop is a chain of
-    // dependent L2 gathers; memory-level parallelism per wave is what bounds it)
-    for (int jc = jb; jc < je; jc += 4) {
-      float v[4][4], fxs[4], fys[4], gas[4];
-      int base[4], Ws[4], bits[4];
+  const float* ow = offw + qrow * rowlen;
+  float lg[2], aw[2];
+  int lev[2];
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const int jj = jc + s_;
-        const int src = (lane & 32) | (jj & 15);
-        const float x = __shfl(px, src, 64), y = __shfl(py, src, 64), a = __shfl(aw, src, 64);
-        const int l = __shfl(l_own, src, 64);
-        const int W = sel4(lv.W, l), H = sel4(lv.H, l);
-        const float xf = floorf(x), yf = floorf(y);
-        fxs[s_] = x - xf; fys[s_] = y - yf;
-        const int x0 = (int)xf, y0 = (int)yf;
-        const bool ok = qlive && jj < je;
-        const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
-        const bool ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
-        bits[s_] = ok ? ((ya && xa) | ((ya && xb) << 1) | ((yb && xa) << 2) | ((yb && xb) << 3)) : 0;
-        base[s_] = sel4(lv.start, l) + y0 * W + x0;
-        Ws[s_] = W;
-        gas[s_] = go * a;
-        v[s_][0] = (bits[s_] & 1) ? vbase[(long long)base[s_] * CH] : 0.f;
-        v[s_][1] = (bits[s_] & 2) ? vbase[(long long)(base[s_] + 1) * CH] : 0.f;
-        v[s_][2] = (bits[s_] & 4) ? vbase[(long long)(base[s_] + W) * CH] : 0.f;
-        v[s_][3] = (bits[s_] & 8) ? vbase[(long long)(base[s_] + W + 1) * CH] : 0.f;
-      }
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const int jj = jc + s_;
-        const float fx = fxs[s_], fy = fys[s_], ga = gas[s_];
-        const int b_ = base[s_] - pix0;
-        if (bits[s_] & 1) atomicAdd(&dval[b_ * HD + c], ga * (1.f - fx) * (1.f - fy));
-        if (bits[s_] & 2) atomicAdd(&dval[(b_ + 1) * HD + c], ga * fx * (1.f - fy));
-        if (bits[s_] & 4) atomicAdd(&dval[(b_ + Ws[s_]) * HD + c], ga * (1.f - fx) * fy);
-        if (bits[s_] & 8) atomicAdd(&dval[(b_ + Ws[s_] + 1) * HD + c], ga * fx * fy);
-        const float v00 = v[s_][0], v01 = v[s_][1], v10 = v[s_][2], v11 = v[s_][3];
-        const float samp = (1.f - fy) * ((1.f - fx) * v00 + fx * v01) + fy * ((1.f - fx) * v10 + fx * v11);
-        const float dsx = (1.f - fy) * (v01 - v00) + fy * (v11 - v10);
-        const float dsy = (1.f - fx) * (v10 - v00) + fx * (v11 - v01);
-        const float r_aw = half_sum32(go * samp);
-        const float r_px = half_sum32(ga * dsx);
-        const float r_py = half_sum32(ga * dsy);
-        if (j == jj && jj < je) { my_daw = r_aw; my_dpx = r_px; my_dpy = r_py; }
-      }
+  for (int s = 0; s < 2; ++s) {
+    const int j = i + 8 * s;
+    const bool live = j < LP;
+    float px = 0.f, py = 0.f;
+    int W = 1, H = 1, st = 0;
+    lg[s] = -INFINITY; lev[s] = 0;
+    if (live) {
+      const int l = j / P;
+      lev[s] = l;
+      W = sel4(lv.W, l); H = sel4(lv.H, l); st = sel4(lv.start, l);
+      const float2 rr = *reinterpret_cast<const float2*>(ref + (qrow * L + l) * 2);
+      const float2 oo = *reinterpret_cast<const float2*>(ow + (h * LP + j) * 2);
+      const float Wf = (float)W, Hf = (float)H;
+      px = (rr.x + oo.x / Wf) * Wf - 0.5f;
+      py = (rr.y + oo.y / Hf) * Hf - 0.5f;
+      lg[s] = ow[HEADS * LP * 2 + h * LP + j];
     }
-    const bool own = qlive && c < 16 && j >= jb && j < je;
-    float* dow = d_offw + qrow * rowlen;
-    if (own) {
-      dow[(h * LP + j) * 2 + 0] = my_dpx;
-      dow[(h * LP + j) * 2 + 1] = my_dpy;
-      dow[HEADS * LP * 2 + h * LP + j] = my_daw;                   // raw d_aw; softmax backward runs afterwards
+    const Tap t = make_tap(px, py, W, H, st, live, S);
+    recs[wv][h * 16 + j] = make_uint4(t.i00 | (t.i01 << 16), t.i10 | (t.i11 << 16), __float_as_uint(t.fx), __float_as_uint(t.fy));
+  }
+  {
+    const float mx = max8(fmaxf(lg[0], lg[1]));
+    const float e0 = __expf(lg[0] - mx), e1 = __expf(lg[1] - mx);
+    const float inv = 1.f / sum8(e0 + e1);
+    aw[0] = e0 * inv; aw[1] = e1 * inv;
+  }
+  const float4 go = *reinterpret_cast<const float4*>(d_out + qrow * CH + h * HD + i * 4);
+  const float* vb = value + (long long)n * S * CH + h * HD + i * 4;
+  float daw[2] = {0.f, 0.f}, dpx[2] = {0.f, 0.f}, dpy[2] = {0.f, 0.f};
+  const uint4* myrec = &recs[wv][h * 16];
+  constexpr int PF = 2;                                          // records / gathers in flight ahead of the consumer
+  uint4 ra[PF + 1];
+  float4 v[PF + 1][4];
+  auto fetch = [&](int j, int slot) {
+    ra[slot] = myrec[j];                                         // same wave wrote it: ordered by lgkmcnt, no barrier
+    const unsigned ids[4] = {ra[slot].x & 0xFFFFu, ra[slot].x >> 16, ra[slot].y & 0xFFFFu, ra[slot].y >> 16};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned idc = min(ids[k], (unsigned)(S - 1));
+      const float4 x = *reinterpret_cast<const float4*>(vb + idc * (unsigned)CH);
+      v[slot][k] = ids[k] < (unsigned)S ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < LP) fetch(j, j);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j >= LP) continue;                                       // uniform; the loop stays fully unrolled
+    if (j + PF < LP) fetch(j + PF, (j + PF) % (PF + 1));
+    const int slot = j % (PF + 1);
+    const float fx = __uint_as_float(ra[slot].z), fy = __uint_as_float(ra[slot].w);
+    const float4 v00 = v[slot][0], v01 = v[slot][1], v10 = v[slot][2], v11 = v[slot][3];
+    float p_aw = 0.f, p_x = 0.f, p_y = 0.f;
+#define CAPE_TAP_CH(C)                                                             \
+    {                                                                              \
+      const float dt = v01.C - v00.C, db = v11.C - v10.C;                          \
+      const float top = v00.C + fx * dt, bot = v10.C + fx * db;                    \
+      p_aw += go.C * (top + fy * (bot - top));                                     \
+      p_x += go.C * (dt + fy * (db - dt));                                         \
+      p_y += go.C * (bot - top);                                                   \
+    }
+    CAPE_TAP_CH(x) CAPE_TAP_CH(y) CAPE_TAP_CH(z) CAPE_TAP_CH(w)
+#undef CAPE_TAP_CH
+    const float r_aw = sum8(p_aw), r_x = sum8(p_x), r_y = sum8(p_y);
+    if (i == (j & 7)) { daw[j >> 3] = r_aw; dpx[j >> 3] = r_x; dpy[j >> 3] = r_y; }
+  }
+  // softmax backward over the head's samples, then the outputs of this lane's two samples
+  const float dot = sum8(aw[0] * daw[0] + aw[1] * daw[1]);
+  float* dow = d_offw + qrow * rowlen;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = i + 8 * s;
+    const bool live = j < LP;
+    const float gx = aw[s] * dpx[s], gy = aw[s] * dpy[s];        // d px / d offset_x = 1 (the 1/W of the offset and the W of px cancel)
+    if (live) {
+      *reinterpret_cast<float2*>(dow + (h * LP + j) * 2) = make_float2(gx, gy);
+      dow[HEADS * LP * 2 + h * LP + j] = aw[s] * (daw[s] - dot);
     }
     if (d_ref) {
-      float rx = own ? my_dpx * (float)sel4(lv.W, l_own) : 0.f;
-      float ry = own ? my_dpy * (float)sel4(lv.H, l_own) : 0.f;
+      // d px / d ref_x = W_l: sum over the P points of a level here, over heads through the atomics
+      float rx = live ? gx * (float)sel4(lv.W, lev[s]) : 0.f;
+      float ry = live ? gy * (float)sel4(lv.H, lev[s]) : 0.f;
       if (P == 4) {
-        rx += __shfl_xor(rx, 1, 64); rx += __shfl_xor(rx, 2, 64);
-        ry += __shfl_xor(ry, 1, 64); ry += __shfl_xor(ry, 2, 64);
-        if (own && (j & 3) == 0) {
-          atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 0], rx);
-          atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 1], ry);
+        rx += dpp_f<0xB1>(rx); rx += dpp_f<0x4E>(rx);
+        ry += dpp_f<0xB1>(ry); ry += dpp_f<0x4E>(ry);
+        if (live && (i & 3) == 0) {
+          atomicAdd(&d_ref[(qrow * L + lev[s]) * 2 + 0], rx);
+          atomicAdd(&d_ref[(qrow * L + lev[s]) * 2 + 1], ry);
         }
-      } else if (own) {
-        atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 0], rx);
-        atomicAdd(&d_ref[(qrow * L + l_own) * 2 + 1], ry);
+      } else if (live) {
+        atomicAdd(&d_ref[(qrow * L + lev[s]) * 2 + 0], rx);
+        atomicAdd(&d_ref[(qrow * L + lev[s]) * 2 + 1], ry);
       }
     }
-  }
-  __syncthreads();
-  float* dvb = d_value + ((long long)n * S + pix0) * CH + h * HD;
-  for (int i = threadIdx.x; i < npix * 8; i += 1024) {
-    const int p_ = i >> 3, c4 = (i & 7) * 4;
-    *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c4) = *reinterpret_cast<const float4*>(&dval[p_ * HD + c4]);
   }
 }
 
-// dlogit = aw * (d_aw - sum_k aw_k d_aw_k) in place on the logit slots of d_offw; thread = (query, head)
-__global__ void msda_softmax_bwd_kernel(const float* __restrict__ offw, float* __restrict__ d_offw, long long rows, int LP) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * HEADS) return;
-  const long long qrow = i >> 3;
-  const int h = (int)(i & 7);
+constexpr int VC = 8;                                            // channels per block of the value kernel
+struct ValRec { uint2 ids; float4 w; };                          // 24 bytes: corner ids + aw * bilinear weights
+
+__global__ void __launch_bounds__(1024) msda_bwd_value_kernel(const float* __restrict__ d_out, const float* __restrict__ offw,
+                                                              const float* __restrict__ ref, float* __restrict__ d_value,
+                                                              Levels lv, int N, int S, int Lq, int L, int P) {
+  extern __shared__ __attribute__((aligned(16))) double slab[];  // [(S + 1)][8]; row S swallows taps outside a level
+  __shared__ uint2 rec_ids[16][64];                              // per wave: [query g (4)][sample j (16)]
+  __shared__ float4 rec_w[16][64];
+  int n, sub;
+  {
+    const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;         // the 32 blocks of an image share an XCD
+    n = (loc >> 5) * 8 + xcd;
+    sub = loc & 31;
+    if (n >= N) return;
+  }
+  const int h = sub >> 2, grp = sub & 3;
+  for (int k = threadIdx.x; k < (S + 1) * VC / 2; k += 1024) reinterpret_cast<double2*>(slab)[k] = make_double2(0.0, 0.0);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;                        // phase 1: (query, sample)
+  const int c = lane & 7, hb = (lane >> 3) & 1;                  // phase 2: channel c, samples 8*hb .. 8*hb+7 of query g
+  const int LP = L * P;
   const int rowlen = HEADS * LP * 3;
-  const float* lg = offw + qrow * rowlen + HEADS * LP * 2 + h * LP;
-  float* dg = d_offw + qrow * rowlen + HEADS * LP * 2 + h * LP;
-  float mx = -INFINITY;
+  const int choff = h * HD + grp * VC + c;
+
+  for (int qb = wv * 4; qb < Lq; qb += 64) {                     // a wave owns 4 queries per trip and needs no barrier
+    const int q = qb + g;
+    const bool qlive = q < Lq;
+    const long long qrow = (long long)n * Lq + (qlive ? q : Lq - 1);
+    {
+      float px = 0.f, py = 0.f, lg = -INFINITY;
+      int W = 1, H = 1, st = 0;
+      const bool slive = qlive && j < LP;
+      if (slive) {
+        const int l = j / P;
+        W = sel4(lv.W, l); H = sel4(lv.H, l); st = sel4(lv.start, l);
+        const float* ow = offw + qrow * rowlen;
+        const float2 rr = *reinterpret_cast<const float2*>(ref + (qrow * L + l) * 2);
+        const float2 oo = *reinterpret_cast<const float2*>(ow + (h * LP + j) * 2);
+        const float Wf = (float)W, Hf = (float)H;
+        px = (rr.x + oo.x / Wf) * Wf - 0.5f;
+        py = (rr.y + oo.y / Hf) * Hf - 0.5f;
+        lg = ow[HEADS * LP * 2 + h * LP + j];
+      }
+      const float mx = max16(lg);
+      const float e = slive ? __expf(lg - mx) : 0.f;
+      const float sm = sum16(e);
+      const float aw = slive ? e / sm : 0.f;
+      const Tap t = make_tap(px, py, W, H, st, slive, S);
+      rec_ids[wv][lane] = make_uint2(t.i00 | (t.i01 << 16), t.i10 | (t.i11 << 16));
+      rec_w[wv][lane] = make_float4(aw * (1.f - t.fx) * (1.f - t.fy), aw * t.fx * (1.f - t.fy), aw * (1.f - t.fx) * t.fy,
+                                    aw * t.fx * t.fy);
+    }
+    const float go = qlive ? d_out[qrow * CH + choff] : 0.f;
+    const int rbase = (lane & 48) + 8 * hb;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) if (k < LP) mx = fmaxf(mx, lg[k]);
-  float e[16], d[16], sm = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { e[k] = k < LP ? __expf(lg[k] - mx) : 0.f; d[k] = k < LP ? dg[k] : 0.f; sm += e[k]; }
-  float dot = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { e[k] /= sm; dot += e[k] * d[k]; }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) if (k < LP) dg[k] = e[k] * (d[k] - dot);
+    for (int s = 0; s < 8; ++s) {
+      const uint2 ids = rec_ids[wv][rbase + s];
+      const float4 w = rec_w[wv][rbase + s];
+      atomicAdd(&slab[(ids.x & 0xFFFFu) * VC + c], (double)(go * w.x));
+      atomicAdd(&slab[(ids.x >> 16) * VC + c], (double)(go * w.y));
+      atomicAdd(&slab[(ids.y & 0xFFFFu) * VC + c], (double)(go * w.z));
+      atomicAdd(&slab[(ids.y >> 16) * VC + c], (double)(go * w.w));
+    }
+  }
+  __syncthreads();
+  float* dvb = d_value + (long long)n * S * CH + h * HD + grp * VC;
+  for (int k = threadIdx.x; k < S * 2; k += 1024) {
+    const int p_ = k >> 1, c4 = (k & 1) * 4;
+    const double* sp = &slab[p_ * VC + c4];
+    *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c4) = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
+  }
 }
 
 int fill_levels(Levels& lv, const int* shapes, const int* level_start, int L, int S) {
@@ -399,55 +495,63 @@ extern "C" int cape_msda_fwd(const float* value, const float* offw, const float*
   return 0;
 }
 
-extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
-                             const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
-                             int N, int S, int Lq, int L, int P, cape_stream_t stream) {
+static int msda_bwd_check(const float* d_out, const float* value, const float* offw, const float* ref, const int* shapes,
+                          const int* level_start, float* d_value, float* d_offw, int L, int P) {
   CAPE_REQUIRE(d_out && value && offw && ref && shapes && level_start && d_value && d_offw, "cape_msda_bwd: null pointer");
   CAPE_REQUIRE(P >= 1 && L * P <= 16, "cape_msda_bwd: L*P=%d must be <= 16", L * P);
+  return 0;
+}
+
+extern "C" int cape_msda_bwd_atomic(const float* d_out, const float* value, const float* offw, const float* ref,
+                                    const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
+                                    int N, int S, int Lq, int L, int P, cape_stream_t stream) {
+  if (msda_bwd_check(d_out, value, offw, ref, shapes, level_start, d_value, d_offw, L, P)) return 1;
   if (N <= 0 || Lq <= 0) return 0;
   Levels lv;
   if (fill_levels(lv, shapes, level_start, L, S)) return 1;
-  // LDS-accumulating form when the (image, head) gradient slabs fit: group A = level 0, group B = the rest
-  const long long pixA = (long long)lv.H[0] * lv.W[0], pixB = (long long)S - pixA;
-  const size_t ldsA = (size_t)pixA * HD * sizeof(float), ldsB = (size_t)pixB * HD * sizeof(float);
-  const size_t kMaxLds = 144 * 1024;
-  // Measured on MI355X (round 1, N=32, S=Lq=1360): the LDS form is SLOWER than memory-side atomics (2.0 ms vs
-  // 1.7 ms per encoder layer): ds_add_f32 throughput per CU is no better than the chip-wide global float-atomic
-  // rate per CU, and one (image, head) per CU leaves too few waves.  Kept opt-in for further tuning.
-  static const bool use_lds = getenv("CAPE_MSDA_BWD_LDS") != nullptr;
-  if (use_lds && L >= 2 && ldsA <= kMaxLds && ldsB <= kMaxLds && (long long)N * HEADS < (1ll << 31)) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-      if (e != hipSuccess) return cape_set_error("cape_msda_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_done = true;
-    }
-    if (d_ref) {
-      hipError_t e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
-      if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(1024), ldsA, as_stream(stream), d_out, value, offw,
-                       ref, d_value, d_offw, d_ref, lv, N, S, Lq, L, P, 0, 1);
-    hipLaunchKernelGGL(msda_bwd_lds_kernel, dim3((unsigned)(N * HEADS)), dim3(1024), ldsB, as_stream(stream), d_out, value, offw,
-                       ref, d_value, d_offw, d_ref, lv, N, S, Lq, L, P, 1, L);
-    const long long rows = (long long)N * Lq;
-    hipLaunchKernelGGL(msda_softmax_bwd_kernel, dim3((unsigned)((rows * HEADS + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       offw, d_offw, rows, L * P);
-    CAPE_LAUNCH_CHECK("cape_msda_bwd(lds)");
-    return 0;
-  }
-  // fallback: memory-side atomics straight into d_value (any geometry); d_value / d_ref are zeroed here
-  {
-    hipError_t e = hipMemsetAsync(d_value, 0, sizeof(float) * (size_t)N * S * CH, as_stream(stream));
-    if (e == hipSuccess && d_ref) e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
-    if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
-  }
+  hipError_t e = hipMemsetAsync(d_value, 0, sizeof(float) * (size_t)N * S * CH, as_stream(stream));
+  if (e == hipSuccess && d_ref) e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
+  if (e != hipSuccess) return cape_set_error("cape_msda_bwd_atomic: memset: %s", hipGetErrorString(e));
   const long long waves = (long long)N * Lq * 4;
   const long long blocks = (waves + 3) / 4;
-  CAPE_REQUIRE(blocks < (1ll << 31), "cape_msda_bwd: grid too large");
+  CAPE_REQUIRE(blocks < (1ll << 31), "cape_msda_bwd_atomic: grid too large");
   hipLaunchKernelGGL(msda_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_out, value, offw, ref,
                      d_value, d_offw, d_ref, lv, N, S, Lq, L, P, waves);
+  CAPE_LAUNCH_CHECK("cape_msda_bwd_atomic");
+  return 0;
+}
+
+extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
+                             const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
+                             int N, int S, int Lq, int L, int P, cape_stream_t stream) {
+  if (msda_bwd_check(d_out, value, offw, ref, shapes, level_start, d_value, d_offw, L, P)) return 1;
+  if (N <= 0 || Lq <= 0) return 0;
+  // split form when the (image, head, 8-channel) fp64 slab fits in LDS (S <= ~2300: every image size up to 320x320);
+  // larger geometries take the memory-side-atomic form
+  const size_t slab_bytes = (size_t)(S + 1) * VC * sizeof(double);
+  const size_t kMaxSlab = 160 * 1024 - 16 * 64 * (sizeof(uint2) + sizeof(float4)) - 512;
+  static const bool force_atomic = getenv("CAPE_MSDA_BWD_ATOMIC") != nullptr;      // tuning switch
+  const long long imgs8 = ((long long)N + 7) / 8;
+  const int bpi = (Lq + 3) / 4;
+  if (force_atomic || slab_bytes > kMaxSlab || S >= 65535 || imgs8 * 8 * 32 >= (1ll << 31) || imgs8 * 8 * bpi >= (1ll << 31))
+    return cape_msda_bwd_atomic(d_out, value, offw, ref, shapes, level_start, d_value, d_offw, d_ref, N, S, Lq, L, P, stream);
+  Levels lv;
+  if (fill_levels(lv, shapes, level_start, L, S)) return 1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
+    if (e != hipSuccess) return cape_set_error("cape_msda_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  if (d_ref) {
+    hipError_t e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
+    if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(msda_bwd_value_kernel, dim3((unsigned)(imgs8 * 8 * 32)), dim3(1024), slab_bytes, as_stream(stream), d_out,
+                     offw, ref, d_value, lv, N, S, Lq, L, P);
+  hipLaunchKernelGGL(msda_bwd_offw_kernel, dim3((unsigned)(imgs8 * 8 * bpi)), dim3(256), 0, as_stream(stream), d_out, value, offw,
+                     ref, d_offw, d_ref, lv, N, S, Lq, L, P, bpi);
   CAPE_LAUNCH_CHECK("cape_msda_bwd");
   return 0;
 }

@@ -54,6 +54,7 @@ _SIGS = {
     "cape_groupnorm_bwd": [P, LL, P, P, P, P, P, P, P, I, I, I, I, P],
     "cape_msda_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_msda_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "cape_msda_bwd_atomic": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_bwd": [P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_add_f32": [P, P, P, LL, P],

@@ -263,12 +263,14 @@ def msda_fwd(value, offw, ref, geo, N, Lq, P=4):
     return out
 
 
-def msda_bwd(d_out, value, offw, ref, geo, N, Lq, P=4, need_ref_grad=True):
+def msda_bwd(d_out, value, offw, ref, geo, N, Lq, P=4, need_ref_grad=True, form="split"):
     _chk(d_out, "msda_bwd.d_out")
     d_value = torch.empty_like(value)
     d_offw = torch.empty_like(offw)
     d_ref = torch.empty_like(ref) if need_ref_grad else None
-    lib.call("cape_msda_bwd", _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
+    # "split": LDS-slab scatter + gather kernel (falls back to atomics inside the library when the slab does not fit)
+    fn = {"split": "cape_msda_bwd", "atomic": "cape_msda_bwd_atomic"}[form]
+    lib.call(fn, _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
              _p(d_offw), _p(d_ref), N, geo.S, Lq, geo.L, P, _stream())
     return d_value, d_offw, d_ref
 

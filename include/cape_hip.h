@@ -136,6 +136,11 @@ int cape_msda_fwd(const float* value, const float* offw, const float* ref, const
 int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
                   const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
                   int N, int S, int Lq, int L, int P, cape_stream_t stream);
+/* any-geometry form of the same backward: memory-side float atomics into d_value (what cape_msda_bwd falls back to when
+ * the (S+1) x 8 fp64 gradient slab of one (image, head, channel group) does not fit in LDS). */
+int cape_msda_bwd_atomic(const float* d_out, const float* value, const float* offw, const float* ref,
+                         const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
+                         int N, int S, int Lq, int L, int P, cape_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small dense attention core, heads of 32 channels packed in rows of `ld` floats:

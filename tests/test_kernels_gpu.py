@@ -218,8 +218,10 @@ def _msda_ref(value, offw, ref, shapes):
 
 
 @pytest.mark.parametrize("N,Lq,shapes", [(2, 37, [(8, 8), (4, 4), (2, 2), (1, 1)]), (9, 5, [(6, 10), (3, 5), (2, 3), (1, 2)]),
-                                         (1, 1360, [(32, 32), (16, 16), (8, 8), (4, 4)])])
-def test_msda_fwd_bwd(N, Lq, shapes):
+                                         (1, 1360, [(32, 32), (16, 16), (8, 8), (4, 4)]),
+                                         (3, 70, [(32, 32), (16, 16), (8, 8), (4, 4)])])
+@pytest.mark.parametrize("form", ["split", "atomic"])
+def test_msda_fwd_bwd(N, Lq, shapes, form):
     value, offw, ref = _msda_inputs(N, Lq, shapes, 11)
     value.requires_grad_(True); offw.requires_grad_(True); ref.requires_grad_(True)
     out_ref = _msda_ref(value, offw, ref, shapes)
@@ -229,10 +231,14 @@ def test_msda_fwd_bwd(N, Lq, shapes):
     vd, od, rd = value.detach().to(DEV), offw.detach().to(DEV), ref.detach().to(DEV)
     out = ops.msda_fwd(vd, od, rd, geo, N, Lq)
     close(out, out_ref, name="msda fwd")
-    dv, do, dr = ops.msda_bwd(go.to(DEV), vd, od, rd, geo, N, Lq)
+    dv, do, dr = ops.msda_bwd(go.to(DEV), vd, od, rd, geo, N, Lq, form=form)
     close(dv, value.grad, tol=3e-4, name="msda d_value")
     close(do, offw.grad, tol=3e-4, name="msda d_offw")
     close(dr, ref.grad, tol=3e-4, name="msda d_ref")
+    dv2, do2, dr2 = ops.msda_bwd(go.to(DEV), vd, od, rd, geo, N, Lq, need_ref_grad=False, form=form)
+    assert dr2 is None
+    close(dv2, value.grad, tol=3e-4, name="msda d_value (no d_ref)")
+    close(do2, offw.grad, tol=3e-4, name="msda d_offw (no d_ref)")
 
 
 def test_msda_core_against_reference_golden(golden_dir):
