@@ -14,6 +14,7 @@
 //   * fp32 MFMA is 64 cycles per 32x32x2 step, so LDS and issue bandwidth are far from binding;
 //     what matters is grid fill (>= 2 tiles per CU or split-K) and L2 locality (XCD-aware tile order).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,14 +25,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (the dropped lo*lo term and the split error are ~2^-16 relative per product; accumulation stays fp32).
 // v_mfma_f32_32x32x16_bf16 issues 16x the flops per cycle of the fp32 MFMA, so the split runs the contraction 16/3
 // faster than exact fp32 at ~fp32 storage traffic.  PREC 0 = exact fp32 MFMA (bitwise an fmaf chain).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// RNE pack of two floats: plain conversions, which the compiler lowers to one v_cvt_pk_bf16_f32 (and, unlike an inline-asm
+// form, schedules with the hazard rules of its consumers in mind)
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
 }
-__device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {
+// lo = x - float(hi) in one instruction each: v_dot2c_f32_bf16 computes hi.x * (-1) + hi.y * 0 + x (both products and the
+// sum are exact: the difference of a float and its bf16 rounding has at most 17 significant bits)
+// The multiplier pairs are {-1, -0} and {-0, -1} rather than {-1, 0} / {0, -1}: the latter are folded into the inline
+// constant "-1.0", whose placement inside a packed-bf16 operand is not what the fold assumes (measured: wrong results).
+// x and y are overwritten with the residuals: the dot2c form accumulates in place, and leaving the inputs dead is what
+// lets the compiler do so without a copy per element
+__device__ __forceinline__ void split2(float& x, float& y, unsigned& hi, unsigned& lo) {
   hi = pk_bf16(x, y);
-  lo = pk_bf16(x - __uint_as_float(hi << 16), y - __uint_as_float(hi & 0xFFFF0000u));
+  const bf16x2 hv = __builtin_bit_cast(bf16x2, hi);
+  x = __builtin_amdgcn_fdot2_f32_bf16(hv, __builtin_bit_cast(bf16x2, 0x8000BF80u), x, false);
+  y = __builtin_amdgcn_fdot2_f32_bf16(hv, __builtin_bit_cast(bf16x2, 0xBF808000u), y, false);
+  lo = pk_bf16(x, y);
 }
 
 namespace {
@@ -65,7 +79,8 @@ __device__ __forceinline__ float4 ldg4(const float* p, int valid) {
 
 constexpr int BK = 32;
 
-template <int BM, int BN, int AMODE, int BMODE, bool VEC, int PREC>
+// KFULL (host-checked: K % 32 == 0): no k-tail handling at all in the loads
+template <int BM, int BN, int AMODE, int BMODE, bool VEC, int PREC, bool KFULL>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   constexpr bool A_KC = (AMODE == 0 || AMODE == 2 || AMODE == 3);
   constexpr bool B_KC = (BMODE == 0);
@@ -164,32 +179,38 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
     }
   }
 
-  float4 ra[NA], rb[NB];
+  // register stages: DEPTH k-tiles of both operands in flight between global memory and the LDS store.  Measured on
+  // MI355X: DEPTH 3 (64x64) / 2 (128x128) is 5-10 % SLOWER than 1 on every shape of tools/gemm_bench.py -- the loop is
+  // bound by instruction issue (VALU split + LDS traffic), not by memory latency, and the extra live registers cost more
+  // than the latency they hide.  The deeper pipeline is kept for tuning.
+  constexpr int DEPTH = 1;
+  float4 ra[DEPTH][NA], rb[DEPTH][NB];
 
   // VEC (host-checked: 16-byte aligned bases, leading dimensions and contiguous extents multiples of 4):
   // every load is an unconditional 16-byte load from a CLAMPED (always valid) address; rows beyond M/N only feed
   // accumulators that the epilogue never stores, chunks beyond K are zeroed with a select -- no branches, no
   // scalar loads in the main loop.  !VEC keeps the guarded element-wise path for odd shapes (K = 2, ld = 3, ...).
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
     const int kbase = kt * BK;
     // ---------------- A ----------------
     if constexpr (AMODE == 0) {
       const int k = kbase + 4 * a_kc;
       if constexpr (VEC) {
-        const bool kin = k < p.K;
+        const bool kin = KFULL || k < p.K;
         const int kc_ = kin ? k : 0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           const int row = min(m0 + a_r0 + 32 * j, p.M - 1);
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long long)row * p.lda + kc_);
-          ra[j] = kin ? v : zero4();
+          ra[sl][j] = kin ? v : zero4();
         }
       } else {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           const int row = m0 + a_r0 + 32 * j;
           const int valid = (row < p.M) ? min(4, max(0, p.K - k)) : 0;
-          ra[j] = valid ? ldg4(p.A + (long long)row * p.lda + k, valid) : zero4();
+          ra[sl][j] = valid ? ldg4(p.A + (long long)row * p.lda + k, valid) : zero4();
         }
       }
     } else if constexpr (AMODE == 1) {
@@ -199,40 +220,40 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           const int k = kbase + (PREC ? 2 * (a_k0 + A_KSTEP * (j >> 1)) + (j & 1) : a_k0 + A_KSTEP * j);
-          const bool kin = k < p.K;
+          const bool kin = KFULL || k < p.K;
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long long)(kin ? k : 0) * p.lda + mc_);
-          ra[j] = kin ? v : zero4();
+          ra[sl][j] = kin ? v : zero4();
         }
       } else {
         const int vm = min(4, max(0, p.M - mcol));
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           const int k = kbase + (PREC ? 2 * (a_k0 + A_KSTEP * (j >> 1)) + (j & 1) : a_k0 + A_KSTEP * j);
-          ra[j] = (k < p.K && vm) ? ldg4(p.A + (long long)k * p.lda + mcol, vm) : zero4();
+          ra[sl][j] = (k < p.K && vm) ? ldg4(p.A + (long long)k * p.lda + mcol, vm) : zero4();
         }
       }
     } else if constexpr (AMODE == 2) {
       const int k = kbase + 4 * a_kc;
-      const int kq = k < p.K ? k : 0;
+      const int kq = (KFULL || k < p.K) ? k : 0;
       const int tap = kq / p.cC, c = kq - tap * p.cC;
       const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int iy = a_y[j] + kh, ix = a_x[j] + kw;
-        const bool ok = (a_n[j] >= 0) && (k < p.K) && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        const bool ok = (a_n[j] >= 0) && (KFULL || k < p.K) && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
         const int nn = max(a_n[j], 0), yy = min(max(iy, 0), p.cH - 1), xx = min(max(ix, 0), p.cW - 1);
         const float4 v = *reinterpret_cast<const float4*>(p.A + (((long long)nn * p.cH + yy) * p.cW + xx) * p.cC + c);
-        ra[j] = ok ? v : zero4();
+        ra[sl][j] = ok ? v : zero4();
       }
     } else {  // AMODE == 3: dgrad gather of dY (N, OH, OW, O); k = tap*O + o
       const int k = kbase + 4 * a_kc;
-      const int kq = k < p.K ? k : 0;
+      const int kq = (KFULL || k < p.K) ? k : 0;
       const int tap = kq / p.cO, o = kq - tap * p.cO;
       const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int ty = a_y[j] - kh, tx = a_x[j] - kw;
-        bool ok = (a_n[j] >= 0) && (k < p.K) && ty >= 0 && tx >= 0;
+        bool ok = (a_n[j] >= 0) && (KFULL || k < p.K) && ty >= 0 && tx >= 0;
         int oy = ty, ox = tx;
         if (p.cStride != 1) {
           oy = ty / p.cStride; ox = tx / p.cStride;
@@ -241,27 +262,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         ok = ok && oy < p.cOH && ox < p.cOW;
         const int nn = max(a_n[j], 0), yy = min(max(oy, 0), p.cOH - 1), xx = min(max(ox, 0), p.cOW - 1);
         const float4 v = *reinterpret_cast<const float4*>(p.A + (((long long)nn * p.cOH + yy) * p.cOW + xx) * p.cO + o);
-        ra[j] = ok ? v : zero4();
+        ra[sl][j] = ok ? v : zero4();
       }
     }
     // ---------------- B ----------------
     if constexpr (BMODE == 0) {
       const int k = kbase + 4 * b_kc;
       if constexpr (VEC) {
-        const bool kin = k < p.K;
+        const bool kin = KFULL || k < p.K;
         const int kc_ = kin ? k : 0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int row = min(n0 + b_r0 + 32 * j, p.N - 1);
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long long)row * p.ldb + kc_);
-          rb[j] = kin ? v : zero4();
+          rb[sl][j] = kin ? v : zero4();
         }
       } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int row = n0 + b_r0 + 32 * j;
           const int valid = (row < p.N) ? min(4, max(0, p.K - k)) : 0;
-          rb[j] = valid ? ldg4(p.B + (long long)row * p.ldb + k, valid) : zero4();
+          rb[sl][j] = valid ? ldg4(p.B + (long long)row * p.ldb + k, valid) : zero4();
         }
       }
     } else if constexpr (BMODE == 1) {
@@ -271,16 +292,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
-          const bool kin = k < p.K;
+          const bool kin = KFULL || k < p.K;
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long long)(kin ? k : 0) * p.ldb + nc_);
-          rb[j] = kin ? v : zero4();
+          rb[sl][j] = kin ? v : zero4();
         }
       } else {
         const int vn = min(4, max(0, p.N - ncol));
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
-          rb[j] = (k < p.K && vn) ? ldg4(p.B + (long long)k * p.ldb + ncol, vn) : zero4();
+          rb[sl][j] = (k < p.K && vn) ? ldg4(p.B + (long long)k * p.ldb + ncol, vn) : zero4();
         }
       }
     } else if constexpr (BMODE == 2) {  // weight (O, KH, KW, C) read as [k = tap*O + o][n = c]
@@ -289,11 +310,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
-        const bool kin = k < p.K;
+        const bool kin = KFULL || k < p.K;
         const int kq = kin ? k : 0;
         const int tap = kq / p.cO, o = kq - tap * p.cO;
         const float4 v = *reinterpret_cast<const float4*>(p.B + ((long long)o * taps + tap) * p.cC + ncol);
-        rb[j] = kin ? v : zero4();
+        rb[sl][j] = kin ? v : zero4();
       }
     } else {  // BMODE == 3: wgrad im2col; k = output position, n = tap*C + c
       const int ncol = min(n0 + 4 * b_mc, p.N - 4);
@@ -303,7 +324,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
-        const bool kin = k < p.K;
+        const bool kin = KFULL || k < p.K;
         const int kq = kin ? k : 0;
         const int ox = kq % p.cOW;
         const int tq = kq / p.cOW;
@@ -313,32 +334,33 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         const bool ok = kin && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
         const int yy = min(max(iy, 0), p.cH - 1), xx = min(max(ix, 0), p.cW - 1);
         const float4 v = *reinterpret_cast<const float4*>(p.B + (((long long)n * p.cH + yy) * p.cW + xx) * p.cC + c);
-        rb[j] = ok ? v : zero4();
+        rb[sl][j] = ok ? v : zero4();
       }
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
     if constexpr (PREC == 0) {
       float* Ad = As[buf];
       float* Bd = Bs[buf];
       if constexpr (A_KC) {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          *reinterpret_cast<float4*>(&Ad[(a_r0 + 32 * j) * A_LD + 4 * a_kc]) = ra[j];
+          *reinterpret_cast<float4*>(&Ad[(a_r0 + 32 * j) * A_LD + 4 * a_kc]) = ra[sl][j];
       } else {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          *reinterpret_cast<float4*>(&Ad[(a_k0 + A_KSTEP * j) * A_LD + 4 * a_mc]) = ra[j];
+          *reinterpret_cast<float4*>(&Ad[(a_k0 + A_KSTEP * j) * A_LD + 4 * a_mc]) = ra[sl][j];
       }
       if constexpr (B_KC) {
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-          *reinterpret_cast<float4*>(&Bd[(b_r0 + 32 * j) * B_LD + 4 * b_kc]) = rb[j];
+          *reinterpret_cast<float4*>(&Bd[(b_r0 + 32 * j) * B_LD + 4 * b_kc]) = rb[sl][j];
       } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-          *reinterpret_cast<float4*>(&Bd[(b_k0 + B_KSTEP * j) * B_LD + 4 * b_mc]) = rb[j];
+          *reinterpret_cast<float4*>(&Bd[(b_k0 + B_KSTEP * j) * B_LD + 4 * b_mc]) = rb[sl][j];
       }
     } else {
       unsigned short* Ah = reinterpret_cast<unsigned short*>(As[buf]);
@@ -349,8 +371,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           unsigned h0, l0, h1, l1;
-          split2(ra[j].x, ra[j].y, h0, l0);
-          split2(ra[j].z, ra[j].w, h1, l1);
+          split2(ra[sl][j].x, ra[sl][j].y, h0, l0);
+          split2(ra[sl][j].z, ra[sl][j].w, h1, l1);
           const int o = (a_r0 + 32 * j) * PL_LD + 4 * a_kc;
           *reinterpret_cast<uint2*>(Ah + o) = make_uint2(h0, h1);
           *reinterpret_cast<uint2*>(Al + o) = make_uint2(l0, l1);
@@ -362,10 +384,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int jj = 0; jj < NA / 2; ++jj) {
           unsigned h[4], l[4];
-          split2(ra[2 * jj].x, ra[2 * jj + 1].x, h[0], l[0]);
-          split2(ra[2 * jj].y, ra[2 * jj + 1].y, h[1], l[1]);
-          split2(ra[2 * jj].z, ra[2 * jj + 1].z, h[2], l[2]);
-          split2(ra[2 * jj].w, ra[2 * jj + 1].w, h[3], l[3]);
+          split2(ra[sl][2 * jj].x, ra[sl][2 * jj + 1].x, h[0], l[0]);
+          split2(ra[sl][2 * jj].y, ra[sl][2 * jj + 1].y, h[1], l[1]);
+          split2(ra[sl][2 * jj].z, ra[sl][2 * jj + 1].z, h[2], l[2]);
+          split2(ra[sl][2 * jj].w, ra[sl][2 * jj + 1].w, h[3], l[3]);
           const int o = (a_k0 + A_KSTEP * jj) * PMA_LD + 4 * a_mc;
           *reinterpret_cast<uint4*>(Ah32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<uint4*>(Ah32 + A_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -375,8 +397,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           unsigned h0, l0, h1, l1;
-          split2(rb[j].x, rb[j].y, h0, l0);
-          split2(rb[j].z, rb[j].w, h1, l1);
+          split2(rb[sl][j].x, rb[sl][j].y, h0, l0);
+          split2(rb[sl][j].z, rb[sl][j].w, h1, l1);
           const int o = (b_r0 + 32 * j) * PL_LD + 4 * b_kc;
           *reinterpret_cast<uint2*>(Bh + o) = make_uint2(h0, h1);
           *reinterpret_cast<uint2*>(Bl + o) = make_uint2(l0, l1);
@@ -386,10 +408,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int jj = 0; jj < NB / 2; ++jj) {
           unsigned h[4], l[4];
-          split2(rb[2 * jj].x, rb[2 * jj + 1].x, h[0], l[0]);
-          split2(rb[2 * jj].y, rb[2 * jj + 1].y, h[1], l[1]);
-          split2(rb[2 * jj].z, rb[2 * jj + 1].z, h[2], l[2]);
-          split2(rb[2 * jj].w, rb[2 * jj + 1].w, h[3], l[3]);
+          split2(rb[sl][2 * jj].x, rb[sl][2 * jj + 1].x, h[0], l[0]);
+          split2(rb[sl][2 * jj].y, rb[sl][2 * jj + 1].y, h[1], l[1]);
+          split2(rb[sl][2 * jj].z, rb[sl][2 * jj + 1].z, h[2], l[2]);
+          split2(rb[sl][2 * jj].w, rb[sl][2 * jj + 1].w, h[3], l[3]);
           const int o = (b_k0 + B_KSTEP * jj) * PMB_LD + 4 * b_mc;
           *reinterpret_cast<uint4*>(Bh32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<uint4*>(Bh32 + B_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -500,12 +522,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   // M-tiles all adding into the same K addresses the float atomics serialise per address (measured: the step got 30 %
   // slower); the standalone colsum kernel with <= 96 fat blocks is faster.
   const bool do_colsum = (AMODE == 0) && p.colsum_out != nullptr && tn == 0;
-  auto colsum_tile = [&](int kt) {
+  auto colsum_tile = [&](int kt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
     if constexpr (AMODE == 0) {
       float4 cs = zero4();
 #pragma unroll
       for (int j = 0; j < NA; ++j)
-        if (m0 + a_r0 + 32 * j < p.M) { cs.x += ra[j].x; cs.y += ra[j].y; cs.z += ra[j].z; cs.w += ra[j].w; }
+        if (m0 + a_r0 + 32 * j < p.M) { cs.x += ra[sl][j].x; cs.y += ra[sl][j].y; cs.z += ra[sl][j].z; cs.w += ra[sl][j].w; }
 #pragma unroll
       for (int o = 8; o < 64; o <<= 1) {
         cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
@@ -521,22 +544,44 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
     }
   };
 
-  load_tiles(kt_begin);
-  if (do_colsum) colsum_tile(kt_begin);
-  store_tiles(0);
-  __syncthreads();
-  if (kt_begin + 1 < kt_end) load_tiles(kt_begin + 1);
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  // software pipeline: tile r (relative to kt_begin) travels in register slot r % DEPTH; LDS is double-buffered.
+  // step r: MFMAs of tile r from LDS[cur] | tile r+1: registers -> LDS[cur^1] | barrier | tile r+1+DEPTH: issue loads
+  auto pipeline_step = [&](int t, int cur, auto NEXT) {            // NEXT = slot of tile t+1
     compute_groups(cur, 0, 2);
-    if (kt + 1 < kt_end) {
-      if (do_colsum) colsum_tile(kt + 1);
-      store_tiles(cur ^ 1);                        // tile kt+1 (in registers since the previous barrier)
+    if (t + 1 < kt_end) {
+      if (do_colsum) colsum_tile(t + 1, NEXT);
+      store_tiles(cur ^ 1, NEXT);
     }
     compute_groups(cur, 2, 4);
-    __syncthreads();                               // all reads of `cur` and writes of `cur^1` are done
-    if (kt + 2 < kt_end) load_tiles(kt + 2);
+    __syncthreads();                                               // all reads of `cur` and writes of `cur^1` are done
+    if (t + 1 + DEPTH < kt_end) load_tiles(t + 1 + DEPTH, NEXT);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1 % DEPTH>;
+  using S2 = std::integral_constant<int, 2 % DEPTH>;
+  load_tiles(kt_begin, S0{});
+  if constexpr (DEPTH >= 2)
+    if (kt_begin + 1 < kt_end) load_tiles(kt_begin + 1, S1{});
+  if constexpr (DEPTH == 3)
+    if (kt_begin + 2 < kt_end) load_tiles(kt_begin + 2, S2{});
+  if (do_colsum) colsum_tile(kt_begin, S0{});
+  store_tiles(0, S0{});
+  if (kt_begin + DEPTH < kt_end) load_tiles(kt_begin + DEPTH, S0{});
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; kt += DEPTH) {
+    pipeline_step(kt, cur, S1{});
     cur ^= 1;
+    if constexpr (DEPTH >= 2) {
+      if (kt + 1 >= kt_end) break;
+      pipeline_step(kt + 1, cur, S2{});
+      cur ^= 1;
+    }
+    if constexpr (DEPTH == 3) {
+      if (kt + 2 >= kt_end) break;
+      pipeline_step(kt + 2, cur, S0{});
+      cur ^= 1;
+    }
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -573,14 +618,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
 
 template <int BM, int BN>
 int launch_mode(const GemmP& p, int a_mode, int b_mode, bool vec, int prec, dim3 grid, hipStream_t s) {
+  const bool kfull = vec && (p.K % BK == 0);
 #define CASE(AM, BM_)                                                                      \
   if (a_mode == AM && b_mode == BM_) {                                                     \
     if (vec && prec == 1) {                                                                \
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 1>), grid, dim3(256), 0, s, p);       \
+      if (kfull) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 1, true>), grid, dim3(256), 0, s, p);   \
+      else hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 1, false>), grid, dim3(256), 0, s, p);        \
       return 0;                                                                            \
     }                                                                                      \
-    if (vec) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 0>), grid, dim3(256), 0, s, p);   \
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, false, 0>), grid, dim3(256), 0, s, p);      \
+    if (vec && kfull) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 0, true>), grid, dim3(256), 0, s, p);   \
+    else if (vec) hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, true, 0, false>), grid, dim3(256), 0, s, p);      \
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, AM, BM_, false, 0, false>), grid, dim3(256), 0, s, p);              \
     return 0;                                                                              \
   }
   CASE(0, 0) CASE(2, 0) CASE(0, 1) CASE(3, 2) CASE(1, 1) CASE(1, 3)
