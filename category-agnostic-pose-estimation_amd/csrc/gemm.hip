@@ -15,56 +15,9 @@
 //     what matters is grid fill (>= 2 tiles per CU or split-K) and L2 locality (XCD-aware tile order).
 #include <stdlib.h>
 #include <type_traits>
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// PREC 1 = "bf16x3": every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits)
-// when it is staged into LDS, and each 16-deep k-step is three bf16 MFMAs hi*hi + hi*lo + lo*hi accumulated in fp32
-// (the dropped lo*lo term and the split error are ~2^-16 relative per product; accumulation stays fp32).
-// v_mfma_f32_32x32x16_bf16 issues 16x the flops per cycle of the fp32 MFMA, so the split runs the contraction 16/3
-// faster than exact fp32 at ~fp32 storage traffic.  PREC 0 = exact fp32 MFMA (bitwise an fmaf chain).
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// RNE pack of two floats: plain conversions, which the compiler lowers to one v_cvt_pk_bf16_f32 (and, unlike an inline-asm
-// form, schedules with the hazard rules of its consumers in mind)
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-  bf16x2 v;
-  v[0] = (__bf16)lo;
-  v[1] = (__bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
-// lo = x - float(hi) in one instruction each: v_dot2c_f32_bf16 computes hi.x * (-1) + hi.y * 0 + x (both products and the
-// sum are exact: the difference of a float and its bf16 rounding has at most 17 significant bits)
-// The multiplier pairs are {-1, -0} and {-0, -1} rather than {-1, 0} / {0, -1}: the latter are folded into the inline
-// constant "-1.0", whose placement inside a packed-bf16 operand is not what the fold assumes (measured: wrong results).
-// x and y are overwritten with the residuals: the dot2c form accumulates in place, and leaving the inputs dead is what
-// lets the compiler do so without a copy per element
-__device__ __forceinline__ void split2(float& x, float& y, unsigned& hi, unsigned& lo) {
-  hi = pk_bf16(x, y);
-  const bf16x2 hv = __builtin_bit_cast(bf16x2, hi);
-  x = __builtin_amdgcn_fdot2_f32_bf16(hv, __builtin_bit_cast(bf16x2, 0x8000BF80u), x, false);
-  y = __builtin_amdgcn_fdot2_f32_bf16(hv, __builtin_bit_cast(bf16x2, 0xBF808000u), y, false);
-  lo = pk_bf16(x, y);
-}
+#include "gemm_common.h"
 
 namespace {
-
-struct GemmP {
-  int M, N, K;
-  const float* A; long long lda;
-  const float* B; long long ldb;
-  float* C; long long ldc;
-  int cN, cH, cW, cC, cKH, cKW, cStride, cPad, cOH, cOW, cO;
-  const float* scale; const float* bias; const float* residual; long long ldr;
-  int relu, accumulate, split_k;
-  float* colsum_out;
-  uint32_t drop_thresh; float inv_keep;
-  const uint64_t* rng_state; uint32_t rng_stream;
-  int tilesM, tilesN;
-};
-
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // guarded 4-float load: `valid` leading elements exist (0..4); vector path needs 16-B alignment
 __device__ __forceinline__ float4 ldg4(const float* p, int valid) {
@@ -76,8 +29,6 @@ __device__ __forceinline__ float4 ldg4(const float* p, int valid) {
   if (valid > 3) r.w = p[3];
   return r;
 }
-
-constexpr int BK = 32;
 
 // KFULL (host-checked: K % 32 == 0): no k-tail handling at all in the loads
 template <int BM, int BN, int AMODE, int BMODE, bool VEC, int PREC, bool KFULL>
@@ -672,22 +623,11 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.inv_keep = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
   p.rng_state = d->rng_state; p.rng_stream = d->rng_stream;
 
-  // tile choice.  Measured on MI355X (tools/gemm_bench.py): with the 64-cycle fp32 MFMA step the 64x64 tile (4 blocks
-  // per CU, 4 waves/SIMD) is never slower than 128x128 and much better balanced on this model's shapes
-  // (M = 43520 = 340 x 128 gives 680 big tiles on 512 slots = 1.33 rounds; 2720 small tiles on 1024 slots waste far
-  // less): 43520x256x256 57 -> 77 TF/s, x1024 74 -> 93 TF/s, 4096^3 118 = 118 TF/s.  128x128 stays available for tuning.
-  bool big = false;
-  {
-    static const char* force = getenv("CAPE_GEMM_TILE");      // tuning override: 64 or 128
-    if (force && force[0] == '1') big = true;
-  }
-  const int BMv = big ? 128 : 64;
-  p.tilesM = (d->M + BMv - 1) / BMv;
-  p.tilesN = (d->N + BMv - 1) / BMv;
-  const long long ntiles = (long long)p.tilesM * p.tilesN;
-  CAPE_REQUIRE(ntiles < (1ll << 31), "cape_gemm_f32: too many tiles");
-  CAPE_REQUIRE(ntiles * d->split_k < (1ll << 31), "cape_gemm_f32: grid too large");
-  dim3 grid((unsigned)(ntiles * d->split_k));
+  p.Bhi = d->B_hi; p.Blo = d->B_lo; p.ldp = d->ldp;
+  if (d->B_hi || d->B_lo) CAPE_REQUIRE(d->B_hi && d->B_lo && d->ldp >= d->K, "cape_gemm_f32: B planes need both pointers and ldp >= K");
+  // weight-stationary kernel when the B operand comes with pre-split planes (see gemm_ws.hip); same epilogue semantics
+  if (d->precision == 1 && cape_gemm_ws_eligible(p, d->a_mode)) return cape_gemm_ws_launch(p, d->a_mode, as_stream(stream));
+
   // vector path: every 16-byte load must be aligned and stay inside its row
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   bool vec = al16(d->A) && al16(d->B);
@@ -698,6 +638,26 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   if (d->b_mode == 2 || d->b_mode == 3) vec = vec && (d->N % 4 == 0) && d->N >= 4;
   if ((d->a_mode >= 2 || d->b_mode >= 2) && !vec) return cape_set_error("cape_gemm_f32: conv modes need the aligned vector path");
   CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
+  // tile choice.  Measured on MI355X (tools/gemm_bench.py): with the 64-cycle fp32 MFMA step the 64x64 tile (4 blocks
+  // per CU, 4 waves/SIMD) is never slower than 128x128 and much better balanced on this model's shapes
+  // (M = 43520 = 340 x 128 gives 680 big tiles on 512 slots = 1.33 rounds; 2720 small tiles on 1024 slots waste far
+  // less): 43520x256x256 57 -> 77 TF/s, x1024 74 -> 93 TF/s, 4096^3 118 = 118 TF/s.  128x128 stays available for tuning.
+  // ... except for deep contractions: with K >= 1024 the 128x128 tile's halved L2 -> L1 traffic per flop wins once there
+  // are enough tiles to cover the chip (measured: 43520x256x1024 134 -> 111 us, 1024x256x43520 split 16 118 -> 111 us)
+  const long long t128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->split_k;
+  bool big = d->K >= 1024 && t128 >= 256 && d->precision == 1 && vec;
+  {
+    static const char* force = getenv("CAPE_GEMM_TILE");      // tuning override: 64 or 128
+    if (force && force[0] == '1') big = true;
+    if (force && force[0] == '6') big = false;
+  }
+  const int BMv = big ? 128 : 64;
+  p.tilesM = (d->M + BMv - 1) / BMv;
+  p.tilesN = (d->N + BMv - 1) / BMv;
+  const long long ntiles = (long long)p.tilesM * p.tilesN;
+  CAPE_REQUIRE(ntiles < (1ll << 31), "cape_gemm_f32: too many tiles");
+  CAPE_REQUIRE(ntiles * d->split_k < (1ll << 31), "cape_gemm_f32: grid too large");
+  dim3 grid((unsigned)(ntiles * d->split_k));
   int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream))
                : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream));
   if (rc) return rc;

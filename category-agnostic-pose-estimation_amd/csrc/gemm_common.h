@@ -1,0 +1,59 @@
+// gemm_common.h -- pieces shared by the GEMM translation units (gemm.hip, gemm_ws.hip).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// PREC 1 = "bf16x3": every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits)
+// when it is staged into LDS, and each 16-deep k-step is three bf16 MFMAs hi*hi + hi*lo + lo*hi accumulated in fp32
+// (the dropped lo*lo term and the split error are ~2^-16 relative per product; accumulation stays fp32).
+// v_mfma_f32_32x32x16_bf16 issues 16x the flops per cycle of the fp32 MFMA, so the split runs the contraction 16/3
+// faster than exact fp32 at ~fp32 storage traffic.  PREC 0 = exact fp32 MFMA (bitwise an fmaf chain).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// RNE pack of two floats: plain conversions, which the compiler lowers to one v_cvt_pk_bf16_f32 (and, unlike an inline-asm
+// form, schedules with the hazard rules of its consumers in mind)
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+// lo = x - float(hi) in one instruction each: v_dot2c_f32_bf16 computes hi.x * (-1) + hi.y * 0 + x (both products and the
+// sum are exact: the difference of a float and its bf16 rounding has at most 17 significant bits)
+// The multiplier pairs are {-1, -0} and {-0, -1} rather than {-1, 0} / {0, -1}: the latter are folded into the inline
+// constant "-1.0", whose placement inside a packed-bf16 operand is not what the fold assumes (measured: wrong results).
+// x and y are overwritten with the residuals: the dot2c form accumulates in place, and leaving the inputs dead is what
+// lets the compiler do so without a copy per element
+__device__ __forceinline__ void split2(float& x, float& y, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(x, y);
+  const bf16x2 hv = __builtin_bit_cast(bf16x2, hi);
+  x = __builtin_amdgcn_fdot2_f32_bf16(hv, __builtin_bit_cast(bf16x2, 0x8000BF80u), x, false);
+  y = __builtin_amdgcn_fdot2_f32_bf16(hv, __builtin_bit_cast(bf16x2, 0xBF808000u), y, false);
+  lo = pk_bf16(x, y);
+}
+
+struct GemmP {
+  int M, N, K;
+  const float* A; long long lda;
+  const float* B; long long ldb;
+  float* C; long long ldc;
+  int cN, cH, cW, cC, cKH, cKW, cStride, cPad, cOH, cOW, cO;
+  const float* scale; const float* bias; const float* residual; long long ldr;
+  int relu, accumulate, split_k;
+  float* colsum_out;
+  uint32_t drop_thresh; float inv_keep;
+  const uint64_t* rng_state; uint32_t rng_stream;
+  int tilesM, tilesN;
+  // pre-split weight planes of the B operand (bf16 bit patterns, [N][K] with leading dimension ldp), or null
+  const unsigned short* Bhi; const unsigned short* Blo; long long ldp;
+};
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+constexpr int BK = 32;
+
+// gemm_ws.hip: weight-stationary bf16x3 kernel (A straight to registers, pre-split B planes through LDS)
+bool cape_gemm_ws_eligible(const GemmP& p, int a_mode);
+int cape_gemm_ws_launch(GemmP& p, int a_mode, hipStream_t stream);
+

@@ -40,6 +40,7 @@ class GemmDesc(ctypes.Structure):
         ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_longlong),
         ("relu", c_int), ("accumulate", c_int), ("split_k", c_int), ("dropout_p", c_float),
         ("rng_state", c_void_p), ("rng_stream", c_uint32), ("colsum_out", c_void_p), ("precision", c_int),
+        ("B_hi", c_void_p), ("B_lo", c_void_p), ("ldp", c_longlong),
     ]
 
 
@@ -47,6 +48,7 @@ P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
 _SIGS = {
     "cape_rng_advance": [P, P],
     "cape_gemm_f32": [POINTER(GemmDesc), P],
+    "cape_split_planes": [P, I, I, I, P, P, P, P, P],
     "cape_colsum_f32": [P, LL, I, LL, I, I, P, I, P],
     "cape_add_layernorm_fwd": [P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
     "cape_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],

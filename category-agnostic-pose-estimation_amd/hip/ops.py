@@ -116,9 +116,24 @@ def get_gemm_precision():
     return {0: "f32", 1: "bf16x3"}[GEMM_PRECISION]
 
 
+def split_planes(W, O, T, C, want_plain=True, want_transposed=True):
+    """bf16 (hi, lo) planes of a weight W viewed as (O, T, C): plain [O][T*C] and/or transposed [C][T*O] (int16 tensors).
+    Returns (hi, lo, hiT, loT) with None for the pair not asked for."""
+    _chk(W, "split_planes.W")
+    assert W.numel() == O * T * C
+    mk = lambda r, c: torch.empty(r, c, dtype=torch.int16, device=W.device)
+    hi = mk(O, T * C) if want_plain else None
+    lo = mk(O, T * C) if want_plain else None
+    hiT = mk(C, T * O) if want_transposed else None
+    loT = mk(C, T * O) if want_transposed else None
+    lib.call("cape_split_planes", _p(W), O, T, C, _p(hi), _p(lo), _p(hiT), _p(loT), _stream())
+    return hi, lo, hiT, loT
+
+
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None,
-         colsum_out=None):
+         colsum_out=None, planes=None):
+    """planes = (hi, lo, ldp): the B operand pre-split into bf16 planes [N][K] (split_planes); optional."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
         _chk(t, "gemm." + n, contiguous=False)
     d = lib.GemmDesc()
@@ -138,6 +153,11 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.rng_state = rng.t.data_ptr() if (rng is not None and dropout_p > 0) else None
     d.rng_stream = rng_stream
     d.precision = GEMM_PRECISION
+    if planes is not None and GEMM_PRECISION == 1:
+        ph, pl, ldp = planes
+        assert ph.dtype == torch.int16 and pl.dtype == torch.int16 and ph.is_cuda and pl.is_cuda
+        assert N == 0 or (_avail(ph) >= (N - 1) * ldp + K and _avail(pl) >= (N - 1) * ldp + K), "gemm: planes too small"
+        d.B_hi, d.B_lo, d.ldp = ph.data_ptr(), pl.data_ptr(), ldp
     if colsum_out is not None:
         _chk(colsum_out, "gemm.colsum_out", contiguous=False)
         assert a_mode == 0 and _avail(colsum_out) >= K

@@ -76,9 +76,20 @@ typedef struct {
                               nn.Linear whose dgrad this GEMM is; atomically accumulated, caller zero-fills) */
   int precision;           /* 0 = exact fp32 MFMA; 1 = bf16x3 split (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32
                               accumulate, ~2^-16 relative per product); odd/unaligned shapes always use 0 */
+  /* optional (precision 1; a_mode 0, 2, 3): the B operand pre-split into bf16 planes laid out [N][K] with leading
+     dimension ldp (cape_split_planes: the as-stored planes of a weight for forward products, the transposed planes
+     for dgrad).  When given and the shape qualifies (K % 32 == 0, aligned rows, conv channels % 16 == 0) the
+     weight-stationary kernel runs; otherwise B / b_mode are used as before.  Must describe the same matrix as B. */
+  const uint16_t* B_hi; const uint16_t* B_lo; long long ldp;
 } cape_gemm_desc;
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
+
+/* Split a weight W (O, T, C) fp32 (nn.Linear: T = 1; channels_last conv weight: T = KH*KW) into bf16 planes
+ * x = hi + lo:  hi/lo [O][T*C] (as stored) and/or hiT/loT [C][T*O] (operand of the transposed product).  Either pair may
+ * be NULL.  Run once per optimizer step per weight; feeds cape_gemm_desc.B_hi/B_lo. */
+int cape_split_planes(const float* W, int O, int T, int C, uint16_t* hi, uint16_t* lo, uint16_t* hiT, uint16_t* loT,
+                      cape_stream_t stream);
 
 /* column sums over nbatch row blocks:  out[n] (+)= sum_b sum_m X[b*batch_stride + m*ldx + n]
  * (bias gradients: nbatch = 1; level_embed gradient: one block of a level's rows per image) */

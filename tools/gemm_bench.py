@@ -34,7 +34,24 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / it
-        print(f"M={M:6d} N={N:5d} K={K:6d} am={am} bm={bm} sk={sk:2d}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+        line = f"M={M:6d} N={N:5d} K={K:6d} am={am} bm={bm} sk={sk:2d}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
+        if am == 0 and sk == 1 and ops.get_gemm_precision() == "bf16x3":      # weight-stationary kernel on the same product
+            if bm == 0:
+                hi, lo, _, _ = ops.split_planes(B, N, 1, K, want_transposed=False)
+            else:
+                _, _, hi, lo = ops.split_planes(B, K, 1, N, want_plain=False)
+            kw["planes"] = (hi, lo, K)
+            for _ in range(3):
+                ops.gemm(A, B, C, M, N, K, **kw)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(it):
+                ops.gemm(A, B, C, M, N, K, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / it
+            line += f"   | ws {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
