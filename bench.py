@@ -177,8 +177,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the steps (launch-bound if ~ the timed region)
     sync()
     dt = time.perf_counter() - t0
+    log(f"host enqueue {t_enq / a.steps * 1e3:.2f} ms/step")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

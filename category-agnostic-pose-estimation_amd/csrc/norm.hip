@@ -193,58 +193,95 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm over NHWC: one block (C threads, thread = channel) per image; three passes over the
-// L2-resident (HW x C) slab: mean, centred variance, normalise.
+// GroupNorm over NHWC, two launches each way so that a level is spread over (N x row chunks) blocks instead of N
+// (the one-block-per-image form ran 32 blocks on 256 CUs: 240 us per level-0 call).  Thread = channel (full 1 KB rows,
+// coalesced), GN_ROWS rows per block.
+//   forward : stats kernel -- per-thread fp32 partial sum / sum of squares over <= GN_ROWS rows, reduced over the
+//             group's lanes, then ONE fp64 atomic pair per (block, group) into ws[n][g][2]; apply kernel -- mean and
+//             variance from the fp64 sums (E[x^2] - E[x]^2 evaluated in double), normalise the chunk.
+//   backward: stats kernel -- per-channel sum(dy), sum(dy * xhat) into ws[n][c][2] (fp32 atomics, <= HW/GN_ROWS adds per
+//             address); apply kernel -- group terms from those sums; the chunk-0 block of every image adds the image's
+//             totals to dgamma / dbeta (N adds per address).
 // ---------------------------------------------------------------------------------------------
+constexpr int GN_ROWS = 16;
+
 __device__ __forceinline__ float group_sum(float v, int cpg) {
   for (int o = 1; o < cpg; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
-__global__ void groupnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float* __restrict__ out,
-                                     long long out_image_stride, float* __restrict__ mean_o,
-                                     float* __restrict__ rstd_o, int HW, int C, int G) {
-  const int n = blockIdx.x, c = threadIdx.x;
+__global__ void groupnorm_stats_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C, int G) {
+  const int n = blockIdx.y, c = threadIdx.x;
   const int cpg = C / G;
+  const int r0 = blockIdx.x * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
   const float* xp = x + (long long)n * HW * C + c;
-  const float cnt = (float)HW * (float)cpg;
-  float s = 0.f;
-  for (int r = 0; r < HW; ++r) s += xp[(long long)r * C];
-  const float mean = group_sum(s, cpg) / cnt;
-  float q = 0.f;
-  for (int r = 0; r < HW; ++r) { const float d = xp[(long long)r * C] - mean; q += d * d; }
-  const float rstd = rsqrtf(group_sum(q, cpg) / cnt + 1e-5f);
-  if ((c % cpg) == 0) { mean_o[n * G + c / cpg] = mean; rstd_o[n * G + c / cpg] = rstd; }
-  const float ga = gamma[c] * rstd, be = beta[c] - mean * gamma[c] * rstd;
-  float* op = out + (long long)n * out_image_stride + c;
-  for (int r = 0; r < HW; ++r) op[(long long)r * C] = xp[(long long)r * C] * ga + be;
+  float s = 0.f, q = 0.f;
+  for (int r = r0; r < r1; ++r) { const float v = xp[(long long)r * C]; s += v; q += v * v; }
+  s = group_sum(s, cpg); q = group_sum(q, cpg);
+  if ((c % cpg) == 0) {
+    double* w = ws + ((long long)n * G + c / cpg) * 2;
+    atomicAdd(w, (double)s);
+    atomicAdd(w + 1, (double)q);
+  }
 }
 
-__global__ void groupnorm_bwd_kernel(const float* __restrict__ d_out, long long d_out_image_stride,
-                                     const float* __restrict__ x, const float* __restrict__ gamma,
-                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                     float* __restrict__ d_x, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int HW, int C, int G) {
-  const int n = blockIdx.x, c = threadIdx.x;
+__global__ void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ out, long long out_image_stride,
+                                       const double* __restrict__ ws, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                       int HW, int C, int G) {
+  const int n = blockIdx.y, c = threadIdx.x;
+  const int cpg = C / G, g = c / cpg;
+  const double cnt = (double)HW * (double)cpg;
+  const double m = ws[((long long)n * G + g) * 2] / cnt;
+  const double var = fmax(ws[((long long)n * G + g) * 2 + 1] / cnt - m * m, 0.0);
+  const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + 1e-5));
+  if (blockIdx.x == 0 && (c % cpg) == 0) { mean_o[n * G + g] = mean; rstd_o[n * G + g] = rstd; }
+  const float ga = gamma[c] * rstd, be = beta[c] - mean * gamma[c] * rstd;
+  const int r0 = blockIdx.x * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
+  const float* xp = x + (long long)n * HW * C + c;
+  float* op = out + (long long)n * out_image_stride + c;
+  for (int r = r0; r < r1; ++r) op[(long long)r * C] = xp[(long long)r * C] * ga + be;
+}
+
+__global__ void groupnorm_bwd_stats_kernel(const float* __restrict__ d_out, long long d_out_image_stride,
+                                           const float* __restrict__ x, const float* __restrict__ mean_i,
+                                           const float* __restrict__ rstd_i, float* __restrict__ ws, int HW, int C, int G) {
+  const int n = blockIdx.y, c = threadIdx.x;
   const int cpg = C / G;
   const float mean = mean_i[n * G + c / cpg], rstd = rstd_i[n * G + c / cpg];
+  const int r0 = blockIdx.x * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
   const float* xp = x + (long long)n * HW * C + c;
   const float* dp = d_out + (long long)n * d_out_image_stride + c;
   float sd = 0.f, sdx = 0.f;
-  for (int r = 0; r < HW; ++r) {
+  for (int r = r0; r < r1; ++r) {
     const float d = dp[(long long)r * C];
     sd += d;
     sdx += d * (xp[(long long)r * C] - mean) * rstd;
   }
-  atomicAdd(&dgamma[c], sdx);
-  atomicAdd(&dbeta[c], sd);
+  float* w = ws + ((long long)n * C + c) * 2;
+  atomicAdd(w, sd);
+  atomicAdd(w + 1, sdx);
+}
+
+__global__ void groupnorm_bwd_apply_kernel(const float* __restrict__ d_out, long long d_out_image_stride,
+                                           const float* __restrict__ x, const float* __restrict__ gamma,
+                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                           const float* __restrict__ ws, float* __restrict__ d_x,
+                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
+  const int n = blockIdx.y, c = threadIdx.x;
+  const int cpg = C / G;
+  const float mean = mean_i[n * G + c / cpg], rstd = rstd_i[n * G + c / cpg];
+  const float sd = ws[((long long)n * C + c) * 2], sdx = ws[((long long)n * C + c) * 2 + 1];
+  if (blockIdx.x == 0) { atomicAdd(&dgamma[c], sdx); atomicAdd(&dbeta[c], sd); }
   const float g = gamma[c];
   const float cnt = (float)HW * (float)cpg;
   const float A = group_sum(g * sd, cpg) / cnt;
   const float B = group_sum(g * sdx, cpg) / cnt;
+  const int r0 = blockIdx.x * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
+  const float* xp = x + (long long)n * HW * C + c;
+  const float* dp = d_out + (long long)n * d_out_image_stride + c;
   float* op = d_x + (long long)n * HW * C + c;
-  for (int r = 0; r < HW; ++r) {
+  for (int r = r0; r < r1; ++r) {
     const float xh = (xp[(long long)r * C] - mean) * rstd;
     op[(long long)r * C] = rstd * (g * dp[(long long)r * C] - A - xh * B);
   }
@@ -296,26 +333,50 @@ static int gn_check(int N, int HW, int C, int G) {
   return 0;
 }
 
+extern "C" size_t cape_groupnorm_workspace_bytes(int N, int C, int G) {
+  if (N <= 0 || C <= 0 || G <= 0) return 0;
+  const size_t f = (size_t)N * G * 2 * sizeof(double), b = (size_t)N * C * 2 * sizeof(float);
+  return f > b ? f : b;
+}
+
 extern "C" int cape_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* out,
                                   long long out_image_stride, float* mean, float* rstd, int N, int HW, int C, int G,
-                                  cape_stream_t stream) {
+                                  void* workspace, size_t workspace_bytes, cape_stream_t stream) {
   CAPE_REQUIRE(x && gamma && beta && out && mean && rstd, "cape_groupnorm_fwd: null pointer");
   if (gn_check(N, HW, C, G)) return 1;
   if (N <= 0 || HW <= 0) return 0;
-  hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3(N), dim3(C), 0, as_stream(stream), x, gamma, beta, out,
-                     out_image_stride, mean, rstd, HW, C, G);
+  const size_t need = (size_t)N * G * 2 * sizeof(double);
+  CAPE_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+               "cape_groupnorm_fwd: workspace of %zu bytes (8-byte aligned) needed, %zu given", need, workspace_bytes);
+  CAPE_REQUIRE(N <= 65535, "cape_groupnorm_fwd: N too large");
+  hipError_t e = hipMemsetAsync(workspace, 0, need, as_stream(stream));
+  if (e != hipSuccess) return cape_set_error("cape_groupnorm_fwd: memset: %s", hipGetErrorString(e));
+  const dim3 grid((HW + GN_ROWS - 1) / GN_ROWS, N);
+  hipLaunchKernelGGL(groupnorm_stats_kernel, grid, dim3(C), 0, as_stream(stream), x, static_cast<double*>(workspace), HW, C, G);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, grid, dim3(C), 0, as_stream(stream), x, gamma, beta, out, out_image_stride,
+                     static_cast<const double*>(workspace), mean, rstd, HW, C, G);
   CAPE_LAUNCH_CHECK("cape_groupnorm_fwd");
   return 0;
 }
 
 extern "C" int cape_groupnorm_bwd(const float* d_out, long long d_out_image_stride, const float* x,
                                   const float* gamma, const float* mean, const float* rstd, float* d_x,
-                                  float* dgamma, float* dbeta, int N, int HW, int C, int G, cape_stream_t stream) {
+                                  float* dgamma, float* dbeta, int N, int HW, int C, int G, void* workspace,
+                                  size_t workspace_bytes, cape_stream_t stream) {
   CAPE_REQUIRE(d_out && x && gamma && mean && rstd && d_x && dgamma && dbeta, "cape_groupnorm_bwd: null pointer");
   if (gn_check(N, HW, C, G)) return 1;
   if (N <= 0 || HW <= 0) return 0;
-  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(N), dim3(C), 0, as_stream(stream), d_out, d_out_image_stride, x,
-                     gamma, mean, rstd, d_x, dgamma, dbeta, HW, C, G);
+  const size_t need = (size_t)N * C * 2 * sizeof(float);
+  CAPE_REQUIRE(workspace && workspace_bytes >= need, "cape_groupnorm_bwd: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+  CAPE_REQUIRE(N <= 65535, "cape_groupnorm_bwd: N too large");
+  hipError_t e = hipMemsetAsync(workspace, 0, need, as_stream(stream));
+  if (e != hipSuccess) return cape_set_error("cape_groupnorm_bwd: memset: %s", hipGetErrorString(e));
+  const dim3 grid((HW + GN_ROWS - 1) / GN_ROWS, N);
+  hipLaunchKernelGGL(groupnorm_bwd_stats_kernel, grid, dim3(C), 0, as_stream(stream), d_out, d_out_image_stride, x, mean, rstd,
+                     static_cast<float*>(workspace), HW, C, G);
+  hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, grid, dim3(C), 0, as_stream(stream), d_out, d_out_image_stride, x, gamma, mean,
+                     rstd, static_cast<const float*>(workspace), d_x, dgamma, dbeta, HW, C, G);
   CAPE_LAUNCH_CHECK("cape_groupnorm_bwd");
   return 0;
 }

@@ -12,7 +12,7 @@ import os
 # "no ROCm-capable device" for torch's pointers (observed when a CPU-only test imported this module first).
 import torch  # noqa: F401  (import order is load order)
 
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_uint32, c_uint64, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_uint32, c_uint64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAPE_HIP_LIB", os.path.join(_HERE, "..", "csrc", "libcape_hip.so"))
@@ -52,8 +52,8 @@ _SIGS = {
     "cape_colsum_f32": [P, LL, I, LL, I, I, P, I, P],
     "cape_add_layernorm_fwd": [P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
     "cape_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
-    "cape_groupnorm_fwd": [P, P, P, P, LL, P, P, I, I, I, I, P],
-    "cape_groupnorm_bwd": [P, LL, P, P, P, P, P, P, P, I, I, I, I, P],
+    "cape_groupnorm_fwd": [P, P, P, P, LL, P, P, I, I, I, I, P, c_size_t, P],
+    "cape_groupnorm_bwd": [P, LL, P, P, P, P, P, P, P, I, I, I, I, P, c_size_t, P],
     "cape_msda_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_msda_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_msda_bwd_atomic": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
@@ -88,7 +88,9 @@ _SIGS = {
     "cape_step_increment": [P, P],
     "cape_decode_next_tokens": [P, P, P, P, P, P, I, I, I, I, I, I, P],
 }
-EXPORTS = ["cape_last_error", "cape_abi_version"] + list(_SIGS)
+EXPORTS = ["cape_last_error", "cape_abi_version", "cape_groupnorm_workspace_bytes"] + list(_SIGS)
+_lib.cape_groupnorm_workspace_bytes.argtypes = [I, I, I]
+_lib.cape_groupnorm_workspace_bytes.restype = c_size_t
 
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)      # AttributeError here = header/library mismatch: fail loudly

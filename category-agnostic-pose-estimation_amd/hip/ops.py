@@ -233,6 +233,11 @@ def add_layernorm_bwd(d_out, d_out_pos, x, y, gamma, mean, rstd, dgamma, dbeta, 
     return d_x, (d_y if d_y is not None else d_x)
 
 
+def _gn_workspace(N, C, G, device):
+    nbytes = lib.raw().cape_groupnorm_workspace_bytes(N, C, G)
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device), nbytes       # fresh per call: stream-ordered reuse
+
+
 def groupnorm_fwd(x, gamma, beta, out, out_image_stride, N, HW, C, G=32):
     for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta")):
         _chk(t, "gn." + n)
@@ -240,16 +245,18 @@ def groupnorm_fwd(x, gamma, beta, out, out_image_stride, N, HW, C, G=32):
     assert x.numel() == N * HW * C
     mean = torch.empty(N * G, dtype=_F32, device=x.device)
     rstd = torch.empty(N * G, dtype=_F32, device=x.device)
+    ws, nbytes = _gn_workspace(N, C, G, x.device)
     lib.call("cape_groupnorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), out_image_stride, _p(mean), _p(rstd), N, HW, C, G,
-             _stream())
+             _p(ws), nbytes, _stream())
     return mean, rstd
 
 
 def groupnorm_bwd(d_out, d_out_image_stride, x, gamma, mean, rstd, dgamma, dbeta, N, HW, C, G=32):
     _chk(d_out, "gn_bwd.d_out", contiguous=False)
     d_x = torch.empty_like(x)
+    ws, nbytes = _gn_workspace(N, C, G, x.device)
     lib.call("cape_groupnorm_bwd", _p(d_out), d_out_image_stride, _p(x), _p(gamma), _p(mean), _p(rstd), _p(d_x),
-             _p(dgamma), _p(dbeta), N, HW, C, G, _stream())
+             _p(dgamma), _p(dbeta), N, HW, C, G, _p(ws), nbytes, _stream())
     return d_x
 
 

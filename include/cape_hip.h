@@ -122,13 +122,16 @@ int cape_add_layernorm_bwd(const float* d_out, const float* d_out_pos, const flo
  * offset.  eps 1e-5.  Replaces nn.GroupNorm(32, hidden_dim) + flatten(2).transpose(1,2) + cat
  * (roomformer_v2.py:192-201, deformable_transformer_v2.py:189-200).
  * ---------------------------------------------------------------------------------------------- */
+/* workspace: cape_groupnorm_workspace_bytes(N, C, G) bytes of device memory (8-byte aligned, contents scratch: the
+ * per-(image, group) fp64 sums of the forward, the per-(image, channel) sums of the backward). */
+size_t cape_groupnorm_workspace_bytes(int N, int C, int G);
 int cape_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* out,
                        long long out_image_stride, float* mean, float* rstd,
-                       int N, int HW, int C, int G, cape_stream_t stream);
+                       int N, int HW, int C, int G, void* workspace, size_t workspace_bytes, cape_stream_t stream);
 int cape_groupnorm_bwd(const float* d_out, long long d_out_image_stride, const float* x,
                        const float* gamma, const float* mean, const float* rstd,
                        float* d_x, float* dgamma, float* dbeta, int N, int HW, int C, int G,
-                       cape_stream_t stream);
+                       void* workspace, size_t workspace_bytes, cape_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-scale deformable attention core (fused softmax over L*P logits + bilinear gather + weighted sum).
