@@ -180,7 +180,11 @@ def main():
     t_enq = time.perf_counter() - t0                 # host time to enqueue the steps (launch-bound if ~ the timed region)
     sync()
     dt = time.perf_counter() - t0
-    log(f"host enqueue {t_enq / a.steps * 1e3:.2f} ms/step")
+    t1 = time.perf_counter()
+    step(a.warmup + a.steps)                         # one step into an empty queue: pure host launch cost, no back-pressure
+    t_one = time.perf_counter() - t1
+    sync()
+    log(f"host enqueue {t_enq / a.steps * 1e3:.2f} ms/step in the timed region; {t_one * 1e3:.2f} ms for one step into an empty queue")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
