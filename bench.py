@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--image_size", type=int, default=256)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph (runtime/graph_step.py) instead of launching every kernel "
+                         "from Python; measured round 1: host cost 30 -> 6 ms per step, wall 38.6 -> 39.7 ms (GPU-bound)")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -148,8 +151,18 @@ def main():
     scale = 1.0 / world
     last = {}
 
-    def step(i):
+    # world == 1: the step is captured into one hipGraph after two eager calls and replayed (runtime/graph_step.py);
+    # data-parallel runs keep the eager step (bucket all-reduces are launched from Python hooks)
+    gstep = None
+    if world == 1 and a.graph:
+        from cape_amd.runtime.graph_step import GraphedTrainStep
+        gstep = GraphedTrainStep(model, crit, opt, loss_scale=scale, edge_capacity=2048, eager_steps=2)
+
+    def step(i, eager=False):
         b = batches[i % len(batches)]
+        if gstep is not None and not eager:
+            last["loss"] = gstep(b["images"], b["support_coords"], b["support_mask"], b["targets"], b["skeleton"])["_total"]
+            return
         rng.advance()
         out = model(samples=b["images"], support_coords=b["support_coords"], support_mask=b["support_mask"],
                     targets=b["targets"], skeleton_edges=b["skeleton"])
@@ -206,7 +219,7 @@ def main():
         torch.cuda.synchronize()
         ops.GemmProfiler.start()
         for i in range(nprof):
-            step(a.warmup + a.steps + i)
+            step(a.warmup + a.steps + i, eager=True)
         r = ops.GemmProfiler.stop()
         HF.Runtime.use_side_stream = side
         if os.environ.get("CAPE_BENCH_GEMM_TABLE"):
@@ -237,16 +250,16 @@ def main():
     if world == 1 and not a.no_roofline and ops.get_gemm_precision() != "f32":
         ops.set_gemm_precision("f32")
         for i in range(2):
-            step(i)
+            step(i, eager=True)
         sync()
         t1 = time.perf_counter()
         nalt = max(2, a.steps // 2)
         for i in range(nalt):
-            step(i)
+            step(i, eager=True)
         sync()
         dta = time.perf_counter() - t1
         ops.set_gemm_precision("bf16x3")
-        alt = {"gemm_precision": "f32 (exact fp32 MFMA)", "value": round(B * nalt / dta, 3), "ms_per_step": round(dta / nalt * 1e3, 3)}
+        alt = {"gemm_precision": "f32 (exact fp32 MFMA)", "launch": "eager", "value": round(B * nalt / dta, 3), "ms_per_step": round(dta / nalt * 1e3, 3)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -270,6 +283,7 @@ def main():
             "model_frac_of_f32_mfma_peak": round(value * gflop_ep / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "gemm_precision": ops.get_gemm_precision(),
             "roofline": roofline, "cpu_baseline": cpu, "alt_exact_f32": alt,
+            "launch": "hipGraph replay of the captured step" if gstep is not None else "eager (one launch per kernel from Python)",
         }
         print(json.dumps(line))
     if world > 1:

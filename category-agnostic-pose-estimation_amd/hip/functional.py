@@ -23,6 +23,7 @@ class Runtime:
     use_side_stream = os.environ.get("CAPE_SIDE_STREAM", "1") == "1"
     side = None
     on_param_grad = []
+    capture_keep = None          # list while a hipGraph capture is in progress (runtime/graph_step.py)
 
     @classmethod
     def side_stream(cls):
@@ -52,6 +53,12 @@ class Runtime:
     @classmethod
     def seed(cls, seed, device):
         cls.rng = ops.RngState(int(seed), device)
+
+
+def capturing():
+    """True while the current stream is being captured into a hipGraph: host decisions that would need a
+    device->host sync take their conservative branch, and cross-stream lifetimes are handled by keeping tensors alive."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def _c(t):
@@ -98,8 +105,13 @@ class _Side:
         if not self.on:
             return False
         self.ctx.__exit__(*a)
-        for t in self.tensors:
-            t.record_stream(self.s)
+        if Runtime.capture_keep is not None:
+            # graph capture: the allocator must not hand these blocks out again inside the captured step (there is no
+            # edge from the side-stream reader to a later main-stream writer); keep them alive until capture ends
+            Runtime.capture_keep.extend(self.tensors)
+        else:
+            for t in self.tensors:
+                t.record_stream(self.s)
         return False
 
 

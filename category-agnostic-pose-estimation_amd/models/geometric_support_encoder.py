@@ -74,7 +74,7 @@ class GeometricSupportEncoder(nn.Module):
         if fast:
             zero = zero | mask
         # (host decision on a tiny bool tensor; one sync per call like the reference's `.any()`)
-        if bool(zero.any()):
+        if HF.capturing() or bool(zero.any()):        # inside a graph capture: always run the (then no-op) kernel
             x = HF.zero_rows(x, zero.reshape(-1).to(torch.uint8).contiguous())
         return x
 

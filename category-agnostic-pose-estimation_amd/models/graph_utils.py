@@ -8,9 +8,40 @@ from ..hip import functional as HF
 from ..hip import ops
 
 
+class DeviceSkeleton:
+    """Edge lists already on the device: `edges` int32 (capacity, 2), `start` int32 (bs + 1) offsets into it.
+    Lets a captured step (runtime/graph_step.py) refresh the skeletons by copying into fixed buffers."""
+
+    def __init__(self, edges, start):
+        self.edges, self.start = edges, start
+
+    def __len__(self):
+        return self.start.numel() - 1
+
+    @staticmethod
+    def flatten(skeleton):
+        flat, start = [], [0]
+        for edges in skeleton:
+            for e in edges:
+                flat.append((int(e[0]), int(e[1])))
+            start.append(len(flat))
+        return flat, start
+
+    @classmethod
+    def from_lists(cls, skeleton, device, capacity=None):
+        flat, start = cls.flatten(skeleton)
+        cap = max(capacity or 0, len(flat), 1)
+        e = torch.zeros(cap, 2, dtype=torch.int32)
+        if flat:
+            e[:len(flat)] = torch.tensor(flat, dtype=torch.int32)
+        return cls(e.to(device), torch.tensor(start, dtype=torch.int32).to(device))
+
+
 def adj_from_skeleton(num_pts, skeleton, mask, device="cuda"):
-    """skeleton: list (len bs) of [[i, j], ...] 0-indexed; mask (bs, num_pts) bool, True = ignore.
+    """skeleton: list (len bs) of [[i, j], ...] 0-indexed, or a DeviceSkeleton; mask (bs, num_pts) bool, True = ignore.
     Returns (bs, 2, num_pts, num_pts): [diag(~mask), row-normalised symmetric adjacency]."""
+    if isinstance(skeleton, DeviceSkeleton):
+        return ops.adjacency(skeleton.edges.contiguous(), skeleton.start, mask.to(torch.uint8).contiguous(), len(skeleton), num_pts)
     bs = len(skeleton)
     flat, start = [], [0]
     for edges in skeleton:

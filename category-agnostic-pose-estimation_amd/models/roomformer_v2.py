@@ -116,7 +116,7 @@ class RoomFormerV2(nn.Module):
             has_padding = not (isinstance(samples, torch.Tensor) and samples.ndim == 4)
             samples = nested_tensor_from_tensor_list(samples)
         elif samples.mask is not None:
-            has_padding = bool(samples.mask.any())
+            has_padding = True if HF.capturing() else bool(samples.mask.any())     # no host sync inside a graph capture
         features = self.backbone(samples)
         srcs, masks = [], []
         last = None

@@ -1,0 +1,102 @@
+"""hipGraph capture of the episodic training step.
+
+One optimizer step of the CAPE path is ~1400 kernel launches (715 GEMMs among them); launched one by one through
+autograd + ctypes they cost ~30 ms of host time, about what the GPU needs to execute them.  The step has static shapes
+for a fixed episode batch geometry, keeps its dropout seed / step counter on the device and decides nothing on the host,
+so the whole of it -- forward, criterion, backward with the side-stream weight gradients, clip + AdamW, zero_grad -- is
+captured once per input-shape signature (after `eager_steps` ordinary calls) and replayed; a replay costs the host three small copies and one launch.
+
+    step = GraphedTrainStep(model, criterion, optimizer)
+    losses = step(images, support_coords, support_mask, targets, skeleton_edges)    # dict of device scalars
+
+Data-parallel runs keep the eager step (the bucket all-reduces are launched from Python hooks)."""
+import torch
+
+from ..hip import functional as HF
+from ..models.graph_utils import DeviceSkeleton
+
+
+def _sig(t):
+    return (tuple(t.shape), str(t.dtype)) if isinstance(t, torch.Tensor) else repr(t)
+
+
+class _Captured:
+    def __init__(self, graph, static_in, static_targets, static_skel, losses, keep):
+        self.graph, self.static_in, self.static_targets, self.static_skel = graph, static_in, static_targets, static_skel
+        self.losses, self.keep = losses, keep
+
+
+class GraphedTrainStep:
+    def __init__(self, model, criterion, optimizer, loss_scale=1.0, edge_capacity=None, max_graphs=8, eager_steps=2):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.loss_scale, self.edge_capacity, self.max_graphs = float(loss_scale), edge_capacity, max_graphs
+        self.eager_steps = eager_steps          # calls per shape signature that run eagerly before the capture
+        self.cache, self.seen = {}, {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _key(self, images, support_coords, support_mask, targets, n_edges):
+        cap = self._capacity(n_edges)
+        return (_sig(images), _sig(support_coords), _sig(support_mask), tuple((k, _sig(v)) for k, v in sorted(targets.items())), cap)
+
+    def _capacity(self, n_edges):
+        if self.edge_capacity is not None:
+            if n_edges > self.edge_capacity:
+                raise ValueError(f"{n_edges} skeleton edges exceed edge_capacity={self.edge_capacity}")
+            return self.edge_capacity
+        return max(64, 1 << (max(n_edges, 1) - 1).bit_length())       # power-of-two buckets keep the graph count small
+
+    def _eager(self, images, support_coords, support_mask, targets, skeleton):
+        HF.Runtime.get_rng(images.device).advance()
+        out = self.model(samples=images, support_coords=support_coords, support_mask=support_mask, targets=targets,
+                         skeleton_edges=skeleton)
+        losses = self.criterion(out, targets)
+        (losses["_total"] * self.loss_scale).backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in losses.items()}
+
+    def _capture(self, images, support_coords, support_mask, targets, skel_lists, cap):
+        dev = images.device
+        s_in = [images.clone(), support_coords.clone(), support_mask.clone()]
+        s_tg = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in targets.items()}
+        s_sk = DeviceSkeleton.from_lists(skel_lists, dev, capacity=cap)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        HF.Runtime.capture_keep = []
+        try:
+            with torch.cuda.graph(g):
+                losses = self._eager(s_in[0], s_in[1], s_in[2], s_tg, s_sk)
+            keep = HF.Runtime.capture_keep
+        finally:
+            HF.Runtime.capture_keep = None
+        return _Captured(g, s_in, s_tg, s_sk, losses, keep)
+
+    # ------------------------------------------------------------------------------------------------
+    def __call__(self, images, support_coords, support_mask, targets, skeleton_edges):
+        if skeleton_edges is None:
+            skeleton_edges = [[] for _ in range(support_coords.shape[0])]
+        flat, start = DeviceSkeleton.flatten(skeleton_edges)
+        key = self._key(images, support_coords, support_mask, targets, len(flat))
+        c = self.cache.get(key)
+        if c is None:
+            n = self.seen.get(key, 0)
+            if n < self.eager_steps:            # first calls run eagerly (allocator pools, lazily set kernel attributes)
+                self.seen[key] = n + 1
+                return self._eager(images, support_coords, support_mask, targets, skeleton_edges)
+            if len(self.cache) >= self.max_graphs:
+                self.cache.pop(next(iter(self.cache)))
+            # capture records the step without executing it; the replay below is this call's one optimizer step
+            c = self.cache[key] = self._capture(images, support_coords, support_mask, targets, skeleton_edges, key[-1])
+            c.graph.replay()
+            return c.losses
+        c.static_in[0].copy_(images, non_blocking=True)
+        c.static_in[1].copy_(support_coords, non_blocking=True)
+        c.static_in[2].copy_(support_mask, non_blocking=True)
+        for k, v in targets.items():
+            if isinstance(v, torch.Tensor):
+                c.static_targets[k].copy_(v, non_blocking=True)
+        if flat:
+            c.static_skel.edges[:len(flat)].copy_(torch.tensor(flat, dtype=torch.int32), non_blocking=False)
+        c.static_skel.start.copy_(torch.tensor(start, dtype=torch.int32), non_blocking=False)
+        c.graph.replay()
+        return c.losses

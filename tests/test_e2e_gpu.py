@@ -204,3 +204,55 @@ def test_arena_direct_grads_and_optimizer_step(golden_dir, proc_sd):
             assert (p.detach().cpu() - q.detach()).abs().max() <= 1e-6, names[id(p)]
     for n, p in opt.dead:                                   # never-grad parameters are untouched
         assert torch.equal(p.detach().cpu(), proc_sd[n])
+
+
+def test_graphed_train_step_matches_eager():
+    """runtime/graph_step.py: replaying the captured step gives the eager step's losses and parameters (same RNG stream)."""
+    import copy
+    from cape_amd.runtime.graph_step import GraphedTrainStep
+    from cape_amd.runtime.optimizer import ArenaAdamW
+    from cape_amd.hip import functional as HF
+    from cape_amd.datasets import DiscreteTokenizerV2, episodic_collate_fn
+    from cape_amd.datasets.synthetic import SyntheticEpisodes
+    from cape_amd.models import build_model
+    from cape_amd.models.cape_model import build_cape_model
+    from cape_amd.models.train_cape_episodic import get_args_parser
+    import argparse
+    args = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(
+        ["--use_geometric_encoder", "--use_gcn_preenc", "--image_size", "64"])
+    tok = DiscreteTokenizerV2(44, args.seq_len)
+    DEV = "cuda"
+    ds = SyntheticEpisodes(tok, 12, 64, 17, 2, seed=5)
+    batches = []
+    for i in range(3):
+        b = episodic_collate_fn([ds[i * 4 + j] for j in range(4)])
+        batches.append((b["query_images"].to(DEV), b["support_coords"].to(DEV), b["support_masks"].to(DEV),
+                        {k: v.to(DEV) for k, v in b["query_targets"].items()}, b["support_skeletons"]))
+
+    def run(graphed):
+        from cape_amd.hip import ops
+        torch.manual_seed(0)
+        ops._stream_counter[0] = 0                            # dropout stream ids are handed out at construction
+        base, crit = build_model(args, tokenizer=tok)
+        model = build_cape_model(args, base).to(DEV)
+        crit = crit.to(DEV)
+        model.train()
+        HF.Runtime.seed(77, DEV)
+        opt = ArenaAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4, max_norm=0.1)
+        step = GraphedTrainStep(model, crit, opt, edge_capacity=512, eager_steps=(1 if graphed else 10 ** 9))
+        losses = []
+        for it in range(5):                                   # call 0 eager, call 1 captures + replays, calls 2.. replay
+            im, sc, sm, tg, sk = batches[it % 3]
+            losses.append(float(step(im, sc, sm, tg, sk)["_total"]))
+        assert (len(step.cache) == 1) == graphed
+        flat = torch.cat([p.detach().reshape(-1)[:64] for p in model.parameters() if p.requires_grad][:40])
+        return losses, flat
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    for a_, b_ in zip(le, lg):
+        assert abs(a_ - b_) <= 2e-4 * max(1.0, abs(a_)), (le, lg)
+    # reduction order differs from run to run (split-K / LDS atomics) and Adam turns a noise-level gradient into a +-lr move:
+    # bound the worst element by steps x lr and ask the bulk to agree closely
+    d = (pe - pg).abs()
+    assert d.max().item() <= 6e-4 and d.mean().item() <= 5e-6, (d.max().item(), d.mean().item())
