@@ -1,4 +1,4 @@
-// attention.hip -- small dense attention core (head dim 32, Lq/Lk <= 256) forward and backward.
+// attention.hip -- small dense attention core (head dim 32) forward (any length, keys tiled by 256) and backward (L <= 256).
 //
 // The CAPE decoder's sequences are tiny (L = 200 tokens, <= 68 support keypoints), so the whole K/V
 // (or Q/dO) panel of one (image, head) lives in LDS (<= 64 KB) and each query (key) row is owned by a
@@ -48,14 +48,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
                                                         const float* __restrict__ V, float* __restrict__ O,
                                                         float* __restrict__ lse, const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // keys are staged in chunks of <= MAXL rows (one chunk for the CAPE decoder's L <= 200; image-token panels of the
+  // bidirectional attention blocks take several), the online softmax state carries across chunks
+  const int KC = min(p.Lk, MAXL);
   float* Ks = smem;
-  float* Vs = smem + p.Lk * HD;
+  float* Vs = smem + KC * HD;
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
   const int i = blockIdx.x * ROWS + (threadIdx.x >> 2);
-  stage_rows(Ks, K + (long long)n * p.bsk + h * HD, p.ldk, p.Lk);
-  stage_rows(Vs, V + (long long)n * p.bsv + h * HD, p.ldv, p.Lk);
-  __syncthreads();
   const bool live = i < p.Lq;
   float q[8], acc[8];
 #pragma unroll
@@ -77,27 +77,36 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   }
   const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
   const uint64_t rbase = (((uint64_t)n * p.H + h) * p.Lq + (uint64_t)(live ? i : 0)) * p.Lk;
-  for (int j = 0; j < jend; ++j) {
-    const float4 k0 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8);
-    const float4 k1 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8 + 4);
-    float s = quad_sum(dot8(q, k0, k1));
-    bool masked = !live;
-    if (p.mask_mode == 1) masked = masked || (j > i + p.causal_offset);
-    if (kp) masked = masked || (kp[j] != 0);
-    if (masked) continue;                      // after the shuffle: safe
-    const float mn = fmaxf(m, s);
-    const float alpha = __expf(m - mn);        // m = -inf on the first unmasked key -> 0
-    const float pe = __expf(s - mn);
-    l = l * alpha + pe;
-    float pd = pe;
-    if (p.thresh) pd = cape_keep(seed, step, p.rng_stream, rbase + j, p.thresh) ? pe * p.inv_keep : 0.f;
-    const float4 v0 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8 + 4);
-    acc[0] = acc[0] * alpha + pd * v0.x; acc[1] = acc[1] * alpha + pd * v0.y;
-    acc[2] = acc[2] * alpha + pd * v0.z; acc[3] = acc[3] * alpha + pd * v0.w;
-    acc[4] = acc[4] * alpha + pd * v1.x; acc[5] = acc[5] * alpha + pd * v1.y;
-    acc[6] = acc[6] * alpha + pd * v1.z; acc[7] = acc[7] * alpha + pd * v1.w;
-    m = mn;
+  for (int k0 = 0; k0 < p.Lk; k0 += MAXL) {
+    const int kc = min(MAXL, p.Lk - k0);
+    if (k0) __syncthreads();                   // everyone is done with the previous chunk
+    stage_rows(Ks, K + (long long)n * p.bsk + (long long)k0 * p.ldk + h * HD, p.ldk, kc);
+    stage_rows(Vs, V + (long long)n * p.bsv + (long long)k0 * p.ldv + h * HD, p.ldv, kc);
+    __syncthreads();
+    const int jhi = min(kc, jend - k0);        // wave-uniform
+    for (int jj = 0; jj < jhi; ++jj) {
+      const int j = k0 + jj;
+      const float4 k0v = *reinterpret_cast<const float4*>(Ks + jj * HD + sub * 8);
+      const float4 k1v = *reinterpret_cast<const float4*>(Ks + jj * HD + sub * 8 + 4);
+      float s = quad_sum(dot8(q, k0v, k1v));
+      bool masked = !live;
+      if (p.mask_mode == 1) masked = masked || (j > i + p.causal_offset);
+      if (kp) masked = masked || (kp[j] != 0);
+      if (masked) continue;                    // after the shuffle: safe
+      const float mn = fmaxf(m, s);
+      const float alpha = __expf(m - mn);      // m = -inf on the first unmasked key -> 0
+      const float pe = __expf(s - mn);
+      l = l * alpha + pe;
+      float pd = pe;
+      if (p.thresh) pd = cape_keep(seed, step, p.rng_stream, rbase + j, p.thresh) ? pe * p.inv_keep : 0.f;
+      const float4 v0 = *reinterpret_cast<const float4*>(Vs + jj * HD + sub * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(Vs + jj * HD + sub * 8 + 4);
+      acc[0] = acc[0] * alpha + pd * v0.x; acc[1] = acc[1] * alpha + pd * v0.y;
+      acc[2] = acc[2] * alpha + pd * v0.z; acc[3] = acc[3] * alpha + pd * v0.w;
+      acc[4] = acc[4] * alpha + pd * v1.x; acc[5] = acc[5] * alpha + pd * v1.y;
+      acc[6] = acc[6] * alpha + pd * v1.z; acc[7] = acc[7] * alpha + pd * v1.w;
+      m = mn;
+    }
   }
   if (live) {
     const float inv = 1.f / l;                 // l == 0 (fully masked row) -> NaN like torch
@@ -246,8 +255,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
 
 int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, const long long* bs, int N, int H, int Lq, int Lk, float scale,
          int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
-         uint32_t rng_stream) {
-  CAPE_REQUIRE(Lq >= 1 && Lk >= 1 && Lq <= MAXL && Lk <= MAXL, "cape_attn: Lq=%d Lk=%d must be in 1..%d", Lq, Lk, MAXL);
+         uint32_t rng_stream, bool fwd = false) {
+  // the forward tiles its keys and takes any length; the backward kernels stage whole panels
+  CAPE_REQUIRE(Lq >= 1 && Lk >= 1 && (fwd || (Lq <= MAXL && Lk <= MAXL)), "cape_attn: Lq=%d Lk=%d must be in 1..%d", Lq, Lk, MAXL);
   CAPE_REQUIRE((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0, "cape_attn: row strides must be multiples of 4");
   CAPE_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "cape_attn: bad mask_mode %d", mask_mode);
   CAPE_REQUIRE(mask_mode != 2 || kpm, "cape_attn: key padding mask missing");
@@ -286,9 +296,10 @@ extern "C" int cape_attn_fwd(const float* Q, const float* K, const float* V, flo
   if (N <= 0 || H <= 0) return 0;
   AttnP p;
   const long long bs[4] = {bsq, bsk, bsv, bso};
-  if (fill(p, ldq, ldk, ldv, ldo, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
+  if (fill(p, ldq, ldk, ldv, ldo, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream, true)) return 1;
   if (raise_lds_limit()) return 1;
-  const size_t sh = (size_t)2 * Lk * HD * sizeof(float);
+  CAPE_REQUIRE((Lq + ROWS - 1) / ROWS <= 65535 * 32, "cape_attn_fwd: Lq too large");
+  const size_t sh = (size_t)2 * (Lk < MAXL ? Lk : MAXL) * HD * sizeof(float);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh, as_stream(stream), Q, K, V, O, lse, p);
   CAPE_LAUNCH_CHECK("cape_attn_fwd");
   return 0;

@@ -257,6 +257,16 @@ __global__ void ref_scale_bwd_kernel(const float* d_in, const float* vr, float* 
     if (acc) d_ref[i] += g; else d_ref[i] = g;
   }
 }
+// exact (erf) GELU, nn.GELU() default
+__global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
+  GSTRIDE(i, n) { const float v = x[i]; out[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+}
+// out[r][c] = x[r][c] + y[r][c] * gamma[c]   (gamma NULL = 1): residual add behind a LayerScale
+__global__ void scale_residual_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gamma,
+                                      float* __restrict__ out, long long rows, int C) {
+  const long long tot = rows * C;
+  GSTRIDE(i, tot) out[i] = x[i] + y[i] * (gamma ? gamma[i % C] : 1.f);
+}
 __global__ void zero_rows_kernel(float* x, const uint8_t* rowmask, long long rows, int C) {
   const long long tot = rows * C;
   GSTRIDE(i, tot) if (rowmask[i / C]) x[i] = 0.f;
@@ -274,6 +284,23 @@ extern "C" int cape_add_f32(const float* a, const float* b, float* out, long lon
                "cape_add_f32: pointers must be 16-byte aligned");
   LAUNCH1(add_kernel, n / 4 + 1, 1, a, b, out, n);
   CAPE_LAUNCH_CHECK("cape_add_f32");
+  return 0;
+}
+
+extern "C" int cape_gelu_f32(const float* x, float* out, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(x && out && n >= 0, "cape_gelu_f32: bad arguments");
+  if (n == 0) return 0;
+  LAUNCH1(gelu_kernel, n, 4, x, out, n);
+  CAPE_LAUNCH_CHECK("cape_gelu_f32");
+  return 0;
+}
+
+extern "C" int cape_scale_residual_f32(const float* x, const float* y, const float* gamma, float* out, long long rows, int C,
+                                       cape_stream_t stream) {
+  CAPE_REQUIRE(x && y && out && rows >= 0 && C > 0, "cape_scale_residual_f32: bad arguments");
+  if (rows == 0) return 0;
+  LAUNCH1(scale_residual_kernel, rows * C, 4, x, y, gamma, out, rows, C);
+  CAPE_LAUNCH_CHECK("cape_scale_residual_f32");
   return 0;
 }
 

@@ -60,6 +60,8 @@ _SIGS = {
     "cape_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_bwd": [P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_add_f32": [P, P, P, LL, P],
+    "cape_gelu_f32": [P, P, LL, P],
+    "cape_scale_residual_f32": [P, P, P, P, LL, I, P],
     "cape_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "cape_bn_fold": [P, P, P, P, F, P, P, I, P],
     "cape_maxpool3x3s2_nhwc": [P, P, I, I, I, I, P],

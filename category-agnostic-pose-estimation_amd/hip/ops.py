@@ -352,6 +352,23 @@ def add(a, b):
     return out
 
 
+def gelu(x):
+    _chk(x, "gelu.x")
+    out = torch.empty_like(x)
+    lib.call("cape_gelu_f32", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
+def scale_residual(x, y, gamma=None):
+    """x + y * gamma (per channel, last dim)."""
+    _chk(x, "scale_residual.x"); _chk(y, "scale_residual.y"); _chk(gamma, "scale_residual.gamma")
+    assert x.shape == y.shape and (gamma is None or gamma.numel() == x.shape[-1])
+    out = torch.empty_like(x)
+    C = x.shape[-1]
+    lib.call("cape_scale_residual_f32", _p(x), _p(y), _p(gamma), _p(out), x.numel() // C, C, _stream())
+    return out
+
+
 def nchw_to_nhwc(x, Cp):
     _chk(x, "nchw_to_nhwc.x")
     N, C, H, W = x.shape

@@ -184,6 +184,11 @@ int cape_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
  * ---------------------------------------------------------------------------------------------- */
 /* out = a + b (n floats, n % 4 == 0 not required) */
 int cape_add_f32(const float* a, const float* b, float* out, long long n, cape_stream_t stream);
+/* out = gelu(x), exact erf form (nn.GELU default; timm Mlp act of models/bixattn.py:116-125) */
+int cape_gelu_f32(const float* x, float* out, long long n, cape_stream_t stream);
+/* out[r][c] = x[r][c] + y[r][c] * gamma[c] (gamma may be NULL): residual behind LayerScale (models/bixattn.py:5-31,135-141) */
+int cape_scale_residual_f32(const float* x, const float* y, const float* gamma, float* out, long long rows, int C,
+                            cape_stream_t stream);
 /* NCHW (N,C,H,W) -> NHWC with channel padding to Cp (zeros) */
 int cape_nchw_to_nhwc(const float* x, float* out, int N, int C, int H, int W, int Cp, cape_stream_t stream);
 /* FrozenBatchNorm fold: scale = w * rsqrt(rv + eps), shift = b - rm * scale  (backbone.py:32-40) */

@@ -663,3 +663,67 @@ def extract_keypoints(pred_coords, token_labels, mask, max_keypoints=None):
     for i, k in enumerate(per):
         out[i, :len(k)] = k
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Bidirectional cross-attention blocks (models/bixattn.py:5-235).  Never executed by the reference's CLI (only the
+# unreachable decoder layer V3 instantiates them, deformable_transformer_v2.py:894-900): class-level restatement.
+# timm.layers.Mlp (requirements_cape.txt:33 `timm>=0.9.0`, not installed offline) is restated from its published
+# definition fc1 -> GELU(erf) -> fc2; DropPath / dropout are identities in eval mode.
+# ------------------------------------------------------------------------------------------------
+def _bix_mlp(x, sd, name):
+    return linear(F.gelu(linear(x, sd, name + ".fc1")), sd, name + ".fc2")
+
+
+def _bix_ls(x, sd, name):
+    g = sd.get(name + ".gamma")
+    return x if g is None else x * g
+
+
+def bixattn(x_lat, x_pat, sd, name, heads=8):
+    """BiXAttn.forward (bixattn.py:63-85): one similarity, softmax over patches for the latents and over latents for the
+    patches."""
+    B, Nl, _ = x_lat.shape
+    Np = x_pat.shape[1]
+    rv_l = linear(x_lat, sd, name + ".rv_latents", bias=(name + ".rv_latents.bias") in sd)
+    rv_p = linear(x_pat, sd, name + ".rv_patches", bias=(name + ".rv_patches.bias") in sd)
+    D = rv_l.shape[-1] // 2
+    hd = D // heads
+    split = lambda t, n: t.reshape(B, n, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    r_l, v_l = split(rv_l, Nl)
+    r_p, v_p = split(rv_p, Np)
+    sim = (r_l @ r_p.transpose(-2, -1)) * hd ** -0.5
+    a = sim.softmax(-1)
+    at = sim.transpose(-2, -1).softmax(-1)
+    out_l = linear((a @ v_p).transpose(1, 2).reshape(B, Nl, D), sd, name + ".proj_lat")
+    out_p = linear((at @ v_l).transpose(1, 2).reshape(B, Np, D), sd, name + ".proj_pat")
+    return out_l, out_p
+
+
+def bixattn_block(x_lat, x_pat, sd, name, heads=8):
+    """BiXAttnBlock.forward (bixattn.py:132-141)."""
+    a_l, a_p = bixattn(layer_norm(x_lat, sd, name + ".norm1_lat"), layer_norm(x_pat, sd, name + ".norm1_pat"), sd, name + ".attn", heads)
+    x_lat = x_lat + _bix_ls(a_l, sd, name + ".ls1_lat")
+    x_lat = x_lat + _bix_ls(_bix_mlp(layer_norm(x_lat, sd, name + ".norm2_lat"), sd, name + ".mlp_lat"), sd, name + ".ls2_lat")
+    x_pat = x_pat + _bix_ls(a_p, sd, name + ".ls1_pat")
+    x_pat = x_pat + _bix_ls(_bix_mlp(layer_norm(x_pat, sd, name + ".norm2_pat"), sd, name + ".mlp_pat"), sd, name + ".ls2_pat")
+    return x_lat, x_pat
+
+
+def ca_one_sided_block(x_lat, x_pat, sd, name, heads=8):
+    """CAOneSidedBlock.forward (bixattn.py:219-235) with CrossAttentionOneSided (:166-181)."""
+    B, Nl, _ = x_lat.shape
+    Np = x_pat.shape[1]
+    xl, xp = layer_norm(x_lat, sd, name + ".norm1_lat"), layer_norm(x_pat, sd, name + ".norm1_pat")
+    an = name + ".attn"
+    r_l = linear(xl, sd, an + ".r_latents", bias=(an + ".r_latents.bias") in sd)
+    rv_p = linear(xp, sd, an + ".rv_patches", bias=(an + ".rv_patches.bias") in sd)
+    D = r_l.shape[-1]
+    hd = D // heads
+    r_l = r_l.reshape(B, Nl, heads, hd).transpose(1, 2)
+    r_p, v_p = rv_p.reshape(B, Np, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    a = ((r_l @ r_p.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    out = linear((a @ v_p).transpose(1, 2).reshape(B, Nl, D), sd, an + ".proj_lat")
+    x_lat = x_lat + _bix_ls(out, sd, name + ".ls1_lat")
+    x_lat = x_lat + _bix_ls(_bix_mlp(layer_norm(x_lat, sd, name + ".norm2_lat"), sd, name + ".mlp_lat"), sd, name + ".ls2_lat")
+    return x_lat

@@ -256,3 +256,31 @@ def test_graphed_train_step_matches_eager():
     # bound the worst element by steps x lr and ask the bulk to agree closely
     d = (pe - pg).abs()
     assert d.max().item() <= 6e-4 and d.mean().item() <= 5e-6, (d.max().item(), d.mean().item())
+
+
+def test_bixattn_blocks_against_reference_golden(golden_dir):
+    """the standalone bidirectional attention blocks against the reference's own classes."""
+    from oracle import procweights
+    from oracle.make_golden_bixattn import inputs
+    from cape_amd.models.bixattn import BiXAttnBlock, CAOneSidedBlock
+    d = np.load(os.path.join(golden_dir, "bixattn.npz"))
+    lat, pat = (x.cuda() for x in inputs())
+
+    def fill(mod, prefix):
+        mod.load_state_dict({k: procweights.tensor_for(prefix + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()}, strict=True)
+        return mod.cuda().eval()
+
+    tol = 2e-5 if _precision() == "f32" else 2e-4
+    ol, op = fill(BiXAttnBlock(256, 256, 256, 8, init_values=0.1), "bixattn.bi")(lat, pat)
+    assert (ol.cpu() - t(d["bi_lat"])).abs().max() <= tol and (op.cpu()[:, ::5] - t(d["bi_pat"])).abs().max() <= tol
+    ol, op = fill(BiXAttnBlock(256, 256, 256, 8, rv_bias=True, init_values=None), "bixattn.bi0")(lat, pat)
+    assert (ol.cpu() - t(d["bi0_lat"])).abs().max() <= 4 * tol and (op.cpu()[:, ::5] - t(d["bi0_pat"])).abs().max() <= 4 * tol
+    oo, none = fill(CAOneSidedBlock(256, 256, 256, 8, init_values=0.1), "bixattn.one")(lat, pat)
+    assert none is None and (oo.cpu() - t(d["one_lat"])).abs().max() <= tol
+    with pytest.raises(RuntimeError):
+        BiXAttnBlock(256, 256, 256, 8).cuda().train()(lat, pat)
+
+
+def _precision():
+    from cape_amd.hip import ops
+    return ops.get_gemm_precision()

@@ -369,6 +369,31 @@ def test_attention_fwd_bwd(N, Lq, Lk, mode):
     assert float(dQ[..., 256:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 300, 700, 0), (1, 1360, 40, 0), (2, 70, 513, 2), (1, 600, 600, 1)])
+def test_attention_fwd_long_sequences(N, Lq, Lk, mode):
+    """Forward with more than 256 keys / queries (keys tiled 256 rows at a time): the bidirectional attention blocks."""
+    H = 8
+    q, k, v = rnd(N, Lq, 256, seed=1), rnd(N, Lk, 256, seed=2), rnd(N, Lk, 256, seed=3)
+    mask, kpm = None, None
+    if mode == 1:
+        mask = torch.triu(torch.full((Lq, Lk), float("-inf")), diagonal=1)
+    if mode == 2:
+        kpm = torch.zeros(N, Lk, dtype=torch.bool)
+        kpm[:, 3] = True; kpm[0, 300:] = True
+        mask = torch.zeros(N, 1, 1, Lk).masked_fill(kpm[:, None, None, :], float("-inf"))
+    ref = _attn_ref(q, k, v, 32 ** -0.5, mask)
+    kpm_d = kpm.to(torch.uint8).to(DEV) if kpm is not None else None
+    O, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), N, H, Lq, Lk, 32 ** -0.5, mask_mode=mode, kpm=kpm_d)
+    close(O, ref, name="attn fwd long")
+
+
+def test_gelu_and_scale_residual():
+    x, y, g = rnd(37, 256, seed=1, scale=2.0), rnd(37, 256, seed=2), rnd(256, seed=3)
+    close(ops.gelu(x.to(DEV)), F.gelu(x), tol=1e-6, name="gelu")
+    close(ops.scale_residual(x.to(DEV), y.to(DEV), g.to(DEV)), x + y * g, tol=1e-6, name="scale_residual")
+    close(ops.scale_residual(x.to(DEV), y.to(DEV)), x + y, tol=1e-6, name="residual")
+
+
 def test_attention_dropout_fwd_bwd_consistent():
     """With dropout the kernel's gradients must be the gradients of its own (masked) forward:
     finite-difference check of sum(O * G) with respect to V (linear in V -> exact up to rounding)."""

@@ -169,3 +169,36 @@ def test_pck_known_answer(golden_dir):
     d = g(golden_dir, "pck.npz")
     r = cape_ref.pck_bbox(d["pred"], d["gt"], float(d["bbox"][0]), float(d["bbox"][1]), d["vis"], 0.2)
     assert abs(r[0] - d["result"][0]) < 1e-12 and r[1] == int(d["result"][1]) and r[2] == int(d["result"][2])
+
+
+def test_bixattn_blocks_match_reference(golden_dir):
+    """the restated bidirectional attention blocks against the reference's own classes (eval mode)."""
+    from oracle import procweights
+    from oracle.make_golden_bixattn import inputs
+    d = np.load(os.path.join(golden_dir, "bixattn.npz"))
+    lat, pat = inputs()
+
+    def sd_for(prefix, keys_shapes):
+        return {prefix + "." + k: procweights.tensor_for(prefix + "." + k, s) for k, s in keys_shapes}
+
+    def block_spec(bias, ls, one_sided):
+        spec = [("norm1_lat.weight", (256,)), ("norm1_lat.bias", (256,)), ("norm1_pat.weight", (256,)), ("norm1_pat.bias", (256,)),
+                ("attn.rv_patches.weight", (512, 256)), ("attn.proj_lat.weight", (256, 256)), ("attn.proj_lat.bias", (256,)),
+                ("norm2_lat.weight", (256,)), ("norm2_lat.bias", (256,)),
+                ("mlp_lat.fc1.weight", (1024, 256)), ("mlp_lat.fc1.bias", (1024,)), ("mlp_lat.fc2.weight", (256, 1024)), ("mlp_lat.fc2.bias", (256,))]
+        spec += [("attn.r_latents.weight", (256, 256))] if one_sided else [("attn.rv_latents.weight", (512, 256))]
+        if not one_sided:
+            spec += [("attn.proj_pat.weight", (256, 256)), ("attn.proj_pat.bias", (256,)), ("norm2_pat.weight", (256,)), ("norm2_pat.bias", (256,)),
+                     ("mlp_pat.fc1.weight", (1024, 256)), ("mlp_pat.fc1.bias", (1024,)), ("mlp_pat.fc2.weight", (256, 1024)), ("mlp_pat.fc2.bias", (256,))]
+        if bias:
+            spec += [("attn.rv_patches.bias", (512,)), ("attn.rv_latents.bias", (512,))]
+        if ls:
+            spec += [("ls1_lat.gamma", (256,)), ("ls2_lat.gamma", (256,))] + ([] if one_sided else [("ls1_pat.gamma", (256,)), ("ls2_pat.gamma", (256,))])
+        return spec
+
+    ol, op = cape_ref.bixattn_block(lat, pat, sd_for("bixattn.bi", block_spec(False, True, False)), "bixattn.bi")
+    assert (ol - torch.from_numpy(d["bi_lat"])).abs().max() <= 1e-5 and (op[:, ::5] - torch.from_numpy(d["bi_pat"])).abs().max() <= 1e-5
+    ol, op = cape_ref.bixattn_block(lat, pat, sd_for("bixattn.bi0", block_spec(True, False, False)), "bixattn.bi0")
+    assert (ol - torch.from_numpy(d["bi0_lat"])).abs().max() <= 2e-5 and (op[:, ::5] - torch.from_numpy(d["bi0_pat"])).abs().max() <= 2e-5
+    oo = cape_ref.ca_one_sided_block(lat, pat, sd_for("bixattn.one", block_spec(False, True, True)), "bixattn.one")
+    assert (oo - torch.from_numpy(d["one_lat"])).abs().max() <= 1e-5
