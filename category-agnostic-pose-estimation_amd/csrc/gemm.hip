@@ -468,30 +468,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
     }
   };
 
-  // optional fused bias gradient (a_mode 0 = dgrad of nn.Linear): colsum_out[k] += sum_m A[m][k] from the A tile in
-  // registers (tn == 0 blocks, rows beyond M masked).  Correct, but NOT used by the training path: with hundreds of
-  // M-tiles all adding into the same K addresses the float atomics serialise per address (measured: the step got 30 %
-  // slower); the standalone colsum kernel with <= 96 fat blocks is faster.
-  const bool do_colsum = (AMODE == 0) && p.colsum_out != nullptr && tn == 0;
-  auto colsum_tile = [&](int kt, auto SLOT) {
+  // optional fused bias gradient (a_mode 1 = wgrad of nn.Linear, A = dY stored [tokens][N_out]):
+  // colsum_out[m] += sum_k A[m][k] over this block's k range, from the A registers on their way to LDS.  Only the
+  // tn == 0 blocks take part, so an address receives split_k atomic adds (<= 64); the same sums fused into the dgrad
+  // (a_mode 0, one add per M-tile: 680 per address) serialised on the float atomics and cost 30 % of the step.
+  // All NA loads of a thread sit in one 4-wide m chunk, so one float4 per thread carries the partial sums.
+  const bool do_colsum = (AMODE == 1) && p.colsum_out != nullptr && tn == 0;
+  float4 csum = zero4();
+  auto colsum_tile = [&](auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
-    if constexpr (AMODE == 0) {
-      float4 cs = zero4();
+    if constexpr (AMODE == 1) {
 #pragma unroll
-      for (int j = 0; j < NA; ++j)
-        if (m0 + a_r0 + 32 * j < p.M) { cs.x += ra[sl][j].x; cs.y += ra[sl][j].y; cs.z += ra[sl][j].z; cs.w += ra[sl][j].w; }
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
-        cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
-      }
-      const int k = kt * BK + 4 * a_kc;
-      if (lane < 8 && k < p.K) {          // K % 4 == 0 on the vector path; the scalar path guards per element
-        atomicAdd(p.colsum_out + k, cs.x);
-        if (k + 1 < p.K) atomicAdd(p.colsum_out + k + 1, cs.y);
-        if (k + 2 < p.K) atomicAdd(p.colsum_out + k + 2, cs.z);
-        if (k + 3 < p.K) atomicAdd(p.colsum_out + k + 3, cs.w);
-      }
+      for (int j = 0; j < NA; ++j) { csum.x += ra[sl][j].x; csum.y += ra[sl][j].y; csum.z += ra[sl][j].z; csum.w += ra[sl][j].w; }
     }
   };
 
@@ -500,7 +488,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   auto pipeline_step = [&](int t, int cur, auto NEXT) {            // NEXT = slot of tile t+1
     compute_groups(cur, 0, 2);
     if (t + 1 < kt_end) {
-      if (do_colsum) colsum_tile(t + 1, NEXT);
+      if (do_colsum) colsum_tile(NEXT);
       store_tiles(cur ^ 1, NEXT);
     }
     compute_groups(cur, 2, 4);
@@ -515,7 +503,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
     if (kt_begin + 1 < kt_end) load_tiles(kt_begin + 1, S1{});
   if constexpr (DEPTH == 3)
     if (kt_begin + 2 < kt_end) load_tiles(kt_begin + 2, S2{});
-  if (do_colsum) colsum_tile(kt_begin, S0{});
+  if (do_colsum) colsum_tile(S0{});
   store_tiles(0, S0{});
   if (kt_begin + DEPTH < kt_end) load_tiles(kt_begin + DEPTH, S0{});
   __syncthreads();
@@ -532,6 +520,26 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
       if (kt + 2 >= kt_end) break;
       pipeline_step(kt + 2, cur, S0{});
       cur ^= 1;
+    }
+  }
+
+  if constexpr (AMODE == 1) {
+    if (do_colsum) {                                               // block-uniform
+      // the main loop ended on a barrier: As is free.  thread t holds chunk a_mc = t % A_CH; fold the 256 / A_CH rows
+      float4* red = reinterpret_cast<float4*>(&As[0][0]);
+      red[t] = csum;
+      __syncthreads();
+      if (t < A_CH) {
+        float4 r = red[t];
+#pragma unroll
+        for (int i = 1; i < 256 / A_CH; ++i) { const float4 u = red[t + A_CH * i]; r.x += u.x; r.y += u.y; r.z += u.z; r.w += u.w; }
+        const int m = m0 + 4 * t;
+        // (a clamped tail chunk of the vector path re-reads valid columns: it must not be counted)
+        if (m < p.M) atomicAdd(p.colsum_out + m, r.x);
+        if (m + 1 < p.M) atomicAdd(p.colsum_out + m + 1, r.y);
+        if (m + 2 < p.M) atomicAdd(p.colsum_out + m + 2, r.z);
+        if (m + 3 < p.M) atomicAdd(p.colsum_out + m + 3, r.w);
+      }
     }
   }
 
@@ -618,7 +626,7 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
   p.relu = d->relu; p.accumulate = d->accumulate; p.split_k = d->split_k;
   p.colsum_out = d->colsum_out;
-  if (d->colsum_out) CAPE_REQUIRE(d->a_mode == 0, "cape_gemm_f32: colsum_out needs a_mode 0");
+  if (d->colsum_out) CAPE_REQUIRE(d->a_mode == 1, "cape_gemm_f32: colsum_out needs a_mode 1 (the wgrad product)");
   p.drop_thresh = d->dropout_p > 0.f ? cape_drop_threshold(d->dropout_p) : 0u;
   p.inv_keep = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
   p.rng_state = d->rng_state; p.rng_stream = d->rng_stream;

@@ -154,10 +154,11 @@ class LinearFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
         if (need_w and wsink is not None) or (need_b and bsink is not None):
             with _Side(dpre, x2):
+                fuse_b = need_b and bsink is not None and need_w and wsink is not None   # bias sums ride in the wgrad
                 if need_w and wsink is not None:
                     ops.gemm(dpre, x2, wsink, N, K, M, a_mode=1, b_mode=1, lda=N, ldb=K, ldc=wsink.stride(0), accumulate=True,
-                             split_k=ops.pick_split_k(N, K, M))
-                if need_b and bsink is not None:
+                             split_k=ops.pick_split_k(N, K, M), colsum_out=bsink if fuse_b else None)
+                if need_b and bsink is not None and not fuse_b:
                     ops.colsum(dpre, M, N, bsink)
             Runtime.notify(_param_of(ctx.w_ref) if (need_w and wsink is not None) else None,
                            _param_of(ctx.b_ref) if (need_b and bsink is not None) else None)
@@ -210,11 +211,10 @@ class LinearCat2Fn(torch.autograd.Function):
         sinks = [_sink(t) for t in ctx.refs]
         if all(k is not None for k in sinks):
             with _Side(dy2, x2):
-                ops.gemm(dy2, x2, sinks[0], N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M))
+                ops.gemm(dy2, x2, sinks[0], N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M),
+                         colsum_out=sinks[1])
                 ops.gemm(dy2[:, N1:], x2, sinks[2], N2, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True,
-                         split_k=ops.pick_split_k(N2, K, M))
-                ops.colsum(dy2, M, N1, sinks[1], ldx=NT)
-                ops.colsum(dy2[:, N1:], M, N2, sinks[3], ldx=NT)
+                         split_k=ops.pick_split_k(N2, K, M), colsum_out=sinks[3])
             Runtime.notify(*[_param_of(t) for t in ctx.refs])
             return dx, None, None, None, None
         dw1 = torch.zeros(N1, K, dtype=torch.float32, device=dev)
@@ -294,19 +294,20 @@ class ConvFn(torch.autograd.Function):
         if need_s:
             src_s = dpre if scale is None else (dres if dres is not None else _mask_only(dy, y, relu))
 
-        def wgrad(dst_phys):
+        def wgrad(dst_phys, bias_sums=None):
             if dense:
                 ops.gemm(dpre, x, dst_phys, O, C, M, a_mode=1, b_mode=1, lda=O, ldb=C, accumulate=True,
-                         split_k=ops.pick_split_k(O, C, M))
+                         split_k=ops.pick_split_k(O, C, M), colsum_out=bias_sums)
             else:
                 ops.gemm(dpre, x, dst_phys, O, K, M, a_mode=1, b_mode=3, lda=O, conv=geom, accumulate=True,
-                         split_k=ops.pick_split_k(O, K, M))
+                         split_k=ops.pick_split_k(O, K, M), colsum_out=bias_sums)
 
         if (need_w and wsink is not None) or (need_s and ssink is not None):
             with _Side(dpre, x, src_s):
+                fuse_s = need_s and ssink is not None and need_w and wsink is not None and src_s is dpre
                 if need_w and wsink is not None:
-                    wgrad(_w_phys(wsink))
-                if need_s and ssink is not None:
+                    wgrad(_w_phys(wsink), ssink if fuse_s else None)
+                if need_s and ssink is not None and not fuse_s:
                     ops.colsum(src_s, M, O, ssink)
             Runtime.notify(_param_of(ctx.w_ref) if (need_w and wsink is not None) else None,
                            _param_of(ctx.shift_ref) if (need_s and ssink is not None) else None)
@@ -554,8 +555,7 @@ class MHAFn(torch.autograd.Function):
 
         def out_grads():
             ops.gemm(d_out2, O.view(-1, C), d_out_w, C, C, Mq, a_mode=1, b_mode=1, accumulate=True,
-                     split_k=ops.pick_split_k(C, C, Mq))
-            ops.colsum(d_out2, Mq, C, d_out_b)
+                     split_k=ops.pick_split_k(C, C, Mq), colsum_out=d_out_b)
 
         if direct:
             with _Side(d_out2, O):
@@ -570,8 +570,7 @@ class MHAFn(torch.autograd.Function):
         def in_grads():
             for i, (g, src, M) in enumerate(((dq, q_in, Mq), (dk, k_in, Mk), (dv, v_in, Mk))):
                 ops.gemm(g.view(-1, C), src.view(-1, C), d_in_w[i * C:], C, C, M, a_mode=1, b_mode=1, accumulate=True,
-                         split_k=ops.pick_split_k(C, C, M))
-                ops.colsum(g.view(-1, C), M, C, d_in_b[i * C:])
+                         split_k=ops.pick_split_k(C, C, M), colsum_out=d_in_b[i * C:])
 
         if direct:
             with _Side(dq, dk, dv, q_in, k_in, v_in):

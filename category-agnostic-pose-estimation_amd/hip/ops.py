@@ -160,7 +160,7 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         d.B_hi, d.B_lo, d.ldp = ph.data_ptr(), pl.data_ptr(), ldp
     if colsum_out is not None:
         _chk(colsum_out, "gemm.colsum_out", contiguous=False)
-        assert a_mode == 0 and _avail(colsum_out) >= K
+        assert a_mode == 1 and _avail(colsum_out) >= M       # fused bias gradient of the wgrad product
         d.colsum_out = colsum_out.data_ptr()
     # host-side extent checks (dense modes)
     if a_mode == 0 and M > 0:

@@ -72,8 +72,9 @@ typedef struct {
   float dropout_p;         /* 0 = off */
   const uint64_t* rng_state;
   uint32_t rng_stream;
-  float* colsum_out;       /* a_mode 0 only, or NULL: colsum_out[k] += sum_m A[m][k] (fused bias gradient of the
-                              nn.Linear whose dgrad this GEMM is; atomically accumulated, caller zero-fills) */
+  float* colsum_out;       /* a_mode 1 only, or NULL: colsum_out[m] += sum_k A[m][k] -- with A = dY stored [tokens][out] this
+                              is the bias gradient of the nn.Linear whose wgrad this GEMM is (atomically accumulated once per
+                              k-split; the caller provides the value to accumulate onto) */
   int precision;           /* 0 = exact fp32 MFMA; 1 = bf16x3 split (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32
                               accumulate, ~2^-16 relative per product); odd/unaligned shapes always use 0 */
   /* optional (precision 1; a_mode 0, 2, 3): the B operand pre-split into bf16 planes laid out [N][K] with leading

@@ -631,12 +631,18 @@ def test_gemm_bf16x3_split_accuracy(M, N, K, am, bm):
     assert errs["bf16x3"] < 4e-5, errs
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 70), (1000, 256, 1024), (43, 64, 36)])
-def test_gemm_fused_colsum(M, N, K):
-    """dgrad GEMM with the fused bias gradient: colsum_out[k] += sum_m A[m][k]."""
-    dy, w = rnd(M, K, seed=1), rnd(K, N, seed=2)
-    out = torch.empty(M, N, device=DEV)
-    cs = torch.full((K,), 2.0, device=DEV)
-    ops.gemm(dy.to(DEV), w.to(DEV), out, M, N, K, a_mode=0, b_mode=1, colsum_out=cs)
-    close(out, dy @ w, name="nn")
-    close(cs, 2.0 + dy.sum(0), tol=2e-4, name="fused colsum")
+@pytest.mark.parametrize("Mo,Ni,Kr,sk", [(256, 256, 3000, 8), (70, 256, 300, 1), (1024, 256, 6400, 16), (260, 36, 100, 1), (384, 256, 5000, 3)])
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+def test_gemm_wgrad_fused_bias_sums(Mo, Ni, Kr, sk, prec):
+    """wgrad GEMM with the fused bias gradient: colsum_out[m] += sum_k A[m][k] (A = dY stored [tokens][out])."""
+    dy, x = rnd(Kr, Mo, seed=1), rnd(Kr, Ni, seed=2)
+    old = ops.get_gemm_precision()
+    try:
+        ops.set_gemm_precision(prec)
+        out = torch.zeros(Mo, Ni, device=DEV)
+        cs = torch.full((Mo,), 2.0, device=DEV)
+        ops.gemm(dy.to(DEV), x.to(DEV), out, Mo, Ni, Kr, a_mode=1, b_mode=1, accumulate=True, split_k=sk, colsum_out=cs)
+    finally:
+        ops.set_gemm_precision(old)
+    close(out, dy.t() @ x, tol=2e-4, name="tn")
+    close(cs, 2.0 + dy.sum(0), tol=2e-4, name="fused bias sums")
