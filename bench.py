@@ -230,8 +230,20 @@ def main():
         # peak for the arithmetic actually issued: exact fp32 MFMA, or bf16 MFMA at three instructions per product
         split = ops.get_gemm_precision() == "bf16x3"
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        # HBM bytes per launch of the family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (tools/gemm_traffic.py, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/; counters cannot be
+        # read from inside the process, so the figure is the committed one, not re-measured by this run
+        traffic, alg_bytes = None, None
+        try:
+            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")))
+            traffic = round(tr["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
+        # algorithmic bytes per launch: A + B + C once each, fp32 (dense formula; an upper bound for the im2col modes)
+        alg_bytes = round(sum(c * 4.0 * (k[0] * k[2] + k[1] * k[2] + k[0] * k[1]) for k, (c, _, _) in r["table"].items()) / max(r["launches"], 1))
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (profiles/r01_gemm_traffic.json)",
+                    "algorithmic_bytes_per_launch": alg_bytes,
                     "peak_note": ("bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product (bf16x3 split)"
                                   if split else "fp32 MFMA dense peak"),
                     "kernel": "gemm_kernel<BM,BN,AMODE,BMODE> (fp32 MFMA implicit GEMM, all instantiations)",

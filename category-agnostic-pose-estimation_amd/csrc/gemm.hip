@@ -568,6 +568,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
         if (p.residual) v += p.residual[(long long)row * p.ldr + col];
         if (p.relu) v = fmaxf(v, 0.f);
         if (drop) v = cape_keep(seed, step, p.rng_stream, (uint64_t)row * (uint64_t)p.N + col, p.drop_thresh) ? v * p.inv_keep : 0.f;
+        if (p.mask_src) v = p.mask_src[(long long)row * p.ldm + col] != 0.f ? v * p.mask_scale : 0.f;
         if (p.accumulate) v += *cp;
         *cp = v;
       }
@@ -632,6 +633,8 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.rng_state = d->rng_state; p.rng_stream = d->rng_stream;
 
   p.Bhi = d->B_hi; p.Blo = d->B_lo; p.ldp = d->ldp;
+  p.mask_src = d->mask_src; p.ldm = d->ldm; p.mask_scale = d->mask_scale;
+  if (d->mask_src) CAPE_REQUIRE(d->split_k == 1, "cape_gemm_f32: mask_src needs split_k == 1");
   if (d->B_hi || d->B_lo) CAPE_REQUIRE(d->B_hi && d->B_lo && d->ldp >= d->K, "cape_gemm_f32: B planes need both pointers and ldp >= K");
   // weight-stationary kernel when the B operand comes with pre-split planes (see gemm_ws.hip); same epilogue semantics
   if (d->precision == 1 && cape_gemm_ws_eligible(p, d->a_mode)) return cape_gemm_ws_launch(p, d->a_mode, as_stream(stream));

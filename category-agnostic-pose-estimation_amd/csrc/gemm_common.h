@@ -47,6 +47,8 @@ struct GemmP {
   int tilesM, tilesN;
   // pre-split weight planes of the B operand (bf16 bit patterns, [N][K] with leading dimension ldp), or null
   const unsigned short* Bhi; const unsigned short* Blo; long long ldp;
+  // optional gate of the result: v = mask_src[m][n] != 0 ? v * mask_scale : 0 (backward of a fused relu/dropout)
+  const float* mask_src; long long ldm; float mask_scale;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
 
 bool cape_gemm_ws_eligible(const GemmP& p, int a_mode) {
   static const bool off = getenv("CAPE_GEMM_NO_WS") != nullptr;    // tuning switch: always use the general kernel
-  if (off || !p.Bhi || !p.Blo || p.split_k != 1 || p.colsum_out) return false;
+  if (off || !p.Bhi || !p.Blo || p.split_k != 1 || p.colsum_out || p.mask_src) return false;
   if (p.K % BK != 0 || p.K <= 0) return false;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!al16(p.A) || !al16(p.Bhi) || !al16(p.Blo) || p.ldp % 8 != 0) return false;

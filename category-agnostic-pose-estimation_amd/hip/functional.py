@@ -178,6 +178,67 @@ def linear(x, weight, bias=None, residual=None, relu=False, dropout_p=0.0, rng_s
     return LinearFn.apply(x, weight, bias, residual, relu, float(dropout_p), int(rng_stream))
 
 
+class FFNFn(torch.autograd.Function):
+    """y = (dropout(relu(x W1^T + b1))) W2^T + b2 -- the transformer feed-forward pair as one node, so that the backward
+    can let the dgrad of the second linear emit the pre-activation gradient of the first directly (GEMM epilogue gated by
+    the saved hidden activation) instead of running a separate relu/dropout-backward pass over the (rows x 1024) tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, dropout_p, rng_stream):
+        K, Hd, N = x.shape[-1], w1.shape[0], w2.shape[0]
+        x2 = _c(x).view(-1, K)
+        M = x2.shape[0]
+        rng = Runtime.get_rng(x.device) if dropout_p > 0 else None
+        h = torch.empty(M, Hd, dtype=torch.float32, device=x.device)
+        ops.gemm(x2, w1, h, M, Hd, K, ldb=w1.stride(0), bias=b1, relu=True, dropout_p=dropout_p, rng=rng, rng_stream=rng_stream)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ops.gemm(h, w2, y, M, N, Hd, ldb=w2.stride(0), bias=b2)
+        ctx.save_for_backward(x2, w1, w2, h)
+        ctx.refs = (w1, b1, w2, b2)
+        ctx.meta = (dropout_p, x.shape, M, K, Hd, N)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h = ctx.saved_tensors
+        p, xshape, M, K, Hd, N = ctx.meta
+        dy2 = _c(dy).view(M, N)
+        # d(pre-activation of linear1) = (dy W2) gated by the saved hidden activation
+        dpre = torch.empty(M, Hd, dtype=torch.float32, device=dy.device)
+        ops.gemm(dy2, w2, dpre, M, Hd, N, a_mode=0, b_mode=1, ldb=w2.stride(0), mask_src=h, mask_scale=1.0 / (1.0 - p) if p > 0 else 1.0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            ops.gemm(dpre, w1, dx, M, K, Hd, a_mode=0, b_mode=1, ldb=w1.stride(0))
+            dx = dx.view(xshape)
+        sinks = [_sink(t) for t in ctx.refs]
+        if all(k is not None for k in sinks) and all(ctx.needs_input_grad[1:5]):
+            with _Side(dy2, dpre, h, x2):
+                ops.gemm(dy2, h, sinks[2], N, Hd, M, a_mode=1, b_mode=1, lda=N, ldb=Hd, ldc=sinks[2].stride(0), accumulate=True,
+                         split_k=ops.pick_split_k(N, Hd, M), colsum_out=sinks[3])
+                ops.gemm(dpre, x2, sinks[0], Hd, K, M, a_mode=1, b_mode=1, lda=Hd, ldb=K, ldc=sinks[0].stride(0), accumulate=True,
+                         split_k=ops.pick_split_k(Hd, K, M), colsum_out=sinks[1])
+            Runtime.notify(*[_param_of(t) for t in ctx.refs])
+            return dx, None, None, None, None, None, None
+        dev = dy.device
+        dw2 = torch.zeros(N, Hd, dtype=torch.float32, device=dev); db2 = torch.zeros(N, dtype=torch.float32, device=dev)
+        dw1 = torch.zeros(Hd, K, dtype=torch.float32, device=dev); db1 = torch.zeros(Hd, dtype=torch.float32, device=dev)
+        ops.gemm(dy2, h, dw2, N, Hd, M, a_mode=1, b_mode=1, lda=N, ldb=Hd, accumulate=True, split_k=ops.pick_split_k(N, Hd, M), colsum_out=db2)
+        ops.gemm(dpre, x2, dw1, Hd, K, M, a_mode=1, b_mode=1, lda=Hd, ldb=K, accumulate=True, split_k=ops.pick_split_k(Hd, K, M), colsum_out=db1)
+        return dx, dw1, db1, dw2, db2, None, None
+
+
+_NO_FFN_FUSE = os.environ.get("CAPE_NO_FFN_FUSE") is not None
+
+
+def ffn(x, w1, b1, w2, b2, dropout_p=0.0, rng_stream=0):
+    """linear2(dropout(relu(linear1(x)))) with both biases (deformable_transformer.py:95,99-100; deformable_transformer_v2.py:
+    314-318; nn.TransformerEncoderLayer's feed-forward in geometric_support_encoder.py)."""
+    if _NO_FFN_FUSE:          # tuning switch: two separate linear nodes (relu/dropout backward as its own pass)
+        return linear(linear(x, w1, b1, relu=True, dropout_p=dropout_p, rng_stream=rng_stream), w2, b2)
+    return FFNFn.apply(x, w1, b1, w2, b2, float(dropout_p), int(rng_stream))
+
+
 class LinearCat2Fn(torch.autograd.Function):
     """[x W1^T + b1 | x W2^T + b2]  (sampling offsets | attention logits of MSDeformAttn)."""
 

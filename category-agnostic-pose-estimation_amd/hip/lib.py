@@ -41,6 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("relu", c_int), ("accumulate", c_int), ("split_k", c_int), ("dropout_p", c_float),
         ("rng_state", c_void_p), ("rng_stream", c_uint32), ("colsum_out", c_void_p), ("precision", c_int),
         ("B_hi", c_void_p), ("B_lo", c_void_p), ("ldp", c_longlong),
+        ("mask_src", c_void_p), ("ldm", c_longlong), ("mask_scale", c_float),
     ]
 
 

@@ -132,7 +132,7 @@ def split_planes(W, O, T, C, want_plain=True, want_transposed=True):
 
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None,
-         colsum_out=None, planes=None):
+         colsum_out=None, planes=None, mask_src=None, mask_scale=1.0):
     """planes = (hi, lo, ldp): the B operand pre-split into bf16 planes [N][K] (split_planes); optional."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
         _chk(t, "gemm." + n, contiguous=False)
@@ -158,6 +158,10 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         assert ph.dtype == torch.int16 and pl.dtype == torch.int16 and ph.is_cuda and pl.is_cuda
         assert N == 0 or (_avail(ph) >= (N - 1) * ldp + K and _avail(pl) >= (N - 1) * ldp + K), "gemm: planes too small"
         d.B_hi, d.B_lo, d.ldp = ph.data_ptr(), pl.data_ptr(), ldp
+    if mask_src is not None:
+        _chk(mask_src, "gemm.mask_src")
+        assert mask_src.numel() == M * N and split_k == 1
+        d.mask_src, d.ldm, d.mask_scale = mask_src.data_ptr(), N, float(mask_scale)
     if colsum_out is not None:
         _chk(colsum_out, "gemm.colsum_out", contiguous=False)
         assert a_mode == 1 and _avail(colsum_out) >= M       # fused bias gradient of the wgrad product

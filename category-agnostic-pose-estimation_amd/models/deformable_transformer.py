@@ -96,8 +96,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
         p = self.dropout1.p if self.training else 0.0
         a = self.self_attn(src_pos, reference_points, src, geo, padding_rows_u8)
         src = HF.add_layernorm(src, a, self.norm1.weight, self.norm1.bias, dropout_p=p, rng_stream=self._streams[0])
-        h = HF.linear(src, self.linear1.weight, self.linear1.bias, relu=True, dropout_p=p, rng_stream=self._streams[1])
-        h = HF.linear(h, self.linear2.weight, self.linear2.bias)
+        h = HF.ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, dropout_p=p,
+                   rng_stream=self._streams[1])
         return HF.add_layernorm(src, h, self.norm2.weight, self.norm2.bias, pos=pos, dropout_p=p, rng_stream=self._streams[2])
 
 

@@ -94,8 +94,7 @@ class TransformerDecoderLayer(nn.Module):
             tgt_pos = HF.add(tgt, query_pos)
         t2 = self.cross_attn(tgt_pos, reference_points, src, geo, padding_rows_u8)
         tgt = HF.add_layernorm(tgt, t2, self.norm1.weight, self.norm1.bias, dropout_p=p, rng_stream=st[4])
-        h = HF.linear(tgt, self.linear1.weight, self.linear1.bias, relu=True, dropout_p=p, rng_stream=st[5])
-        h = HF.linear(h, self.linear2.weight, self.linear2.bias)
+        h = HF.ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, dropout_p=p, rng_stream=st[5])
         return HF.add_layernorm(tgt, h, self.norm3.weight, self.norm3.bias, dropout_p=p, rng_stream=st[6])
 
     # ---- cached single-token step (inference only) -------------------------------------------------

@@ -67,8 +67,8 @@ class GeometricSupportEncoder(nn.Module):
             a = HF.mha(x, x, x, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.nhead,
                        mask_mode=2, kpm_u8=kpm, dropout_p=p, rng_stream=st[0])
             x = HF.add_layernorm(x, a, layer.norm1.weight, layer.norm1.bias, dropout_p=p, rng_stream=st[1])
-            hdn = HF.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True, dropout_p=p, rng_stream=st[2])
-            hdn = HF.linear(hdn, layer.linear2.weight, layer.linear2.bias)
+            hdn = HF.ffn(x, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, dropout_p=p,
+                         rng_stream=st[2])
             x = HF.add_layernorm(x, hdn, layer.norm2.weight, layer.norm2.bias, dropout_p=p, rng_stream=st[3])
         zero = all_masked[:, None].expand(bs, num_pts)
         if fast:

@@ -47,7 +47,7 @@ int cape_rng_advance(uint64_t* rng_state, cape_stream_t stream);
  *         2 conv weight read as [(kh,kw,o)][c]   -- conv dgrad
  *         3 conv-wgrad im2col gather, k = output position, n = (kh, kw, c)
  * Epilogue (split_k == 1): v = acc; v = v*scale[n] (opt); v += bias[n] (opt); v += residual[m][n] (opt);
- *   relu (opt); dropout(p) (opt, applied last); then C = v or C += v (accumulate).
+ *   relu (opt); dropout(p) (opt); gate by mask_src (opt, see the struct); then C = v or C += v (accumulate).
  * split_k > 1: partial sums are atomically added into C (C must hold the value to accumulate onto);
  *   no other epilogue op is allowed.
  * Replaces: F.linear / nn.Conv2d + FrozenBatchNorm2d (+ReLU, +residual) and their autograd
@@ -82,6 +82,10 @@ typedef struct {
      for dgrad).  When given and the shape qualifies (K % 32 == 0, aligned rows, conv channels % 16 == 0) the
      weight-stationary kernel runs; otherwise B / b_mode are used as before.  Must describe the same matrix as B. */
   const uint16_t* B_hi; const uint16_t* B_lo; long long ldp;
+  /* optional gate applied last (split_k == 1): v = mask_src[m][n] != 0 ? v * mask_scale : 0, mask_src (M, ldm).  With
+     mask_src = the saved output of a fused linear+ReLU(+dropout p) and mask_scale = 1/(1-p), the dgrad of the *next*
+     layer emits the pre-activation gradient directly (FFN backward without a separate relu/dropout-backward pass). */
+  const float* mask_src; long long ldm; float mask_scale;
 } cape_gemm_desc;
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);

@@ -182,6 +182,28 @@ def test_gemm_ws_conv_fwd_and_dgrad(N, H, W, C, O, k, stride, pad):
     close(dx.view(N, H, W, C).permute(0, 3, 1, 2), x.grad, tol=2e-4, name="ws conv dgrad")
 
 
+def test_gemm_mask_epilogue_and_ffn_autograd():
+    """dgrad with the gate epilogue (v = mask != 0 ? v * s : 0) and the fused feed-forward node against torch autograd."""
+    from cape_amd.hip import functional as HF
+    M, K, Hd = 333, 256, 1024
+    dy, w2, hmask = rnd(M, K, seed=1), rnd(K, Hd, seed=2, scale=K ** -0.5), F.relu(rnd(M, Hd, seed=3))
+    out = torch.empty(M, Hd, device=DEV)
+    ops.gemm(dy.to(DEV), w2.to(DEV), out, M, Hd, K, a_mode=0, b_mode=1, mask_src=hmask.to(DEV), mask_scale=1.25)
+    close(out, (dy @ w2) * (hmask != 0) * 1.25, name="gated dgrad")
+    x = rnd(2, 50, 256, seed=4).requires_grad_(True)
+    w1, b1 = rnd(Hd, 256, seed=5, scale=256 ** -0.5).requires_grad_(True), rnd(Hd, seed=6).requires_grad_(True)
+    w2p, b2 = rnd(256, Hd, seed=7, scale=Hd ** -0.5).requires_grad_(True), rnd(256, seed=8).requires_grad_(True)
+    ref = F.linear(F.relu(F.linear(x, w1, b1)), w2p, b2)
+    g = rnd(2, 50, 256, seed=9)
+    ref.backward(g)
+    dev = [t.detach().to(DEV).requires_grad_(True) for t in (x, w1, b1, w2p, b2)]
+    y = HF.ffn(*dev)
+    close(y, ref, name="ffn fwd")
+    y.backward(g.to(DEV))
+    for got, want, nm in zip(dev, (x, w1, b1, w2p, b2), ("dx", "dw1", "db1", "dw2", "db2")):
+        close(got.grad, want.grad, tol=2e-4, name="ffn " + nm)
+
+
 def test_gemm_dropout_epilogue_statistics_and_replay():
     M, N, K = 512, 256, 64
     x, w = torch.ones(M, K, device=DEV), torch.ones(N, K, device=DEV)
