@@ -86,7 +86,7 @@ class CAPEModel(nn.Module):
         return outputs
 
     def forward_inference(self, samples, support_coords, support_mask, skeleton_edges=None, max_seq_len=None, use_cache=True,
-                          teacher_stream=None):
+                          teacher_stream=None, graph=None):
         if support_mask.dtype != torch.bool:
             support_mask = support_mask.bool()
         encoder_mask = ~support_mask
@@ -94,7 +94,8 @@ class CAPEModel(nn.Module):
         self._inject(support_features, support_mask)
         try:
             with torch.no_grad():
-                outputs = self.base_model.forward_inference(samples=samples, use_cache=use_cache, teacher_stream=teacher_stream)
+                outputs = self.base_model.forward_inference(samples=samples, use_cache=use_cache, teacher_stream=teacher_stream,
+                                                             graph=graph)
         finally:
             self._clear()
         pred_logits = outputs.get("pred_logits")

@@ -58,6 +58,7 @@ class RoomFormerV2(nn.Module):
         self.num_feature_levels = num_feature_levels
         self.tokenizer = tokenizer
         self.seq_len = seq_len
+        self._decode_states = {}       # batch geometry -> static decode buffers + captured step graphs (forward_inference)
         self.patch_size = patch_size
         self.inject_cls_embed = inject_cls_embed
         num_backbone_outs = len(backbone.strides)
@@ -155,14 +156,23 @@ class RoomFormerV2(nn.Module):
     # ---- KV-cached autoregressive inference -------------------------------------------------------
     @torch.no_grad()
     def forward_inference(self, samples, use_cache=True, support_graphs=None, support_mask=None, sync_every=8,
-                          teacher_stream=None):
+                          teacher_stream=None, graph=None):
         """Generates until every sample has emitted <eos> (after >= 6 steps) or `tokenizer.seq_len` steps.
         Token bookkeeping (roomformer_v2.py:521-598) runs on the device; the host only polls the
         `unfinished` flags every `sync_every` steps, then trims to the step at which the reference's loop
         would have stopped (identical outputs: steps after the stop only feed <pad> tokens).
-        `teacher_stream` (dict of (N,T) token/delta tensors) replaces the model's own feedback for parity tests."""
+        `teacher_stream` (dict of (N,T) token/delta tensors) replaces the model's own feedback for parity tests.
+
+        graph (default: env CAPE_DECODE_GRAPH, on): a decode step is ~170 launches of 32-row kernels, i.e. host-bound
+        (2.7 ms per step against ~0.7 ms of GPU work), so the steps are captured as hipGraphs -- one per step index,
+        because the cache row written, the attention length and the output slot are baked into the launch arguments -- over
+        a set of static state buffers per batch geometry.  The first call for a geometry runs eagerly, the second
+        captures while it decodes, later calls replay."""
         if not use_cache:
             raise ValueError("the MI355X path always decodes with caches (use_cache=False is a debugging mode of the reference)")
+        if graph is None:
+            graph = os.environ.get("CAPE_DECODE_GRAPH", "1") == "1"
+        graph = graph and teacher_stream is None
         enc = self._encode_images(samples)
         dec = self.transformer.decoder
         geo, vr, memory = enc["geo"], enc["valid_ratios"], enc["memory"]
@@ -172,40 +182,77 @@ class RoomFormerV2(nn.Module):
         min_len = 6
         support = getattr(dec, "support_features", None)
         smask = getattr(dec, "support_mask", None)
-        caches = []
-        for layer in dec.layers:
-            c = {"k": torch.zeros(N, self.seq_len, 256, device=dev), "v": torch.zeros(N, self.seq_len, 256, device=dev),
-                 "value": layer.cross_attn.project_value(memory, enc["pad_rows"]), "sup_k": None, "sup_v": None, "sup_kpm": None}
-            if support is not None:
+        P = support.shape[1] if support is not None else 0
+
+        # ---- state buffers (static per geometry when graphs are used) ----
+        key = (N, tuple(geo.shapes), P, smask is not None, max_len, str(dev), ops.get_gemm_precision())
+        st = self._decode_states.get(key) if graph else None
+        fresh = st is None
+        if fresh:
+            st = {"calls": 0, "graphs": {}, "pool": None,
+                  "vr": torch.empty_like(vr), "ref_all": torch.empty(self.query_embed.weight.shape[0], 2, device=dev),
+                  "toks": torch.empty(4, N, dtype=torch.int64, device=dev), "deltas": torch.empty(4, N, device=dev),
+                  "unfinished": torch.empty(N, dtype=torch.int32, device=dev), "step_t": torch.zeros(1, dtype=torch.int32, device=dev),
+                  "out_logits": torch.zeros(N, max_len, self.num_classes, device=dev), "out_coords": torch.zeros(N, max_len, 2, device=dev),
+                  "out_hs": torch.zeros(N, max_len, 256, device=dev), "alive_after": torch.zeros(max_len, dtype=torch.int32, device=dev),
+                  "caches": [{"k": torch.zeros(N, self.seq_len, 256, device=dev), "v": torch.zeros(N, self.seq_len, 256, device=dev),
+                              "value": torch.empty(N, geo.S, 256, device=dev),
+                              "sup_k": torch.empty(N, P, 256, device=dev) if P else None,
+                              "sup_v": torch.empty(N, P, 256, device=dev) if P else None,
+                              "sup_kpm": torch.empty(N, P, dtype=torch.uint8, device=dev) if (P and smask is not None) else None}
+                             for _ in dec.layers]}
+            if graph:
+                if len(self._decode_states) >= 4:
+                    self._decode_states.pop(next(iter(self._decode_states)))
+                self._decode_states[key] = st
+        st["calls"] += 1
+        caches = st["caches"]
+        for layer, c in zip(dec.layers, caches):
+            c["value"].copy_(layer.cross_attn.project_value(memory, enc["pad_rows"]))
+            if P:
                 ca = layer.support_attn
-                P = support.shape[1]
-                c["sup_k"] = torch.empty(N, P, 256, device=dev); c["sup_v"] = torch.empty(N, P, 256, device=dev)
                 s2 = support.contiguous().view(N * P, 256)
                 ops.gemm(s2, ca.in_proj_weight[256:], c["sup_k"], N * P, 256, 256, bias=ca.in_proj_bias[256:])
                 ops.gemm(s2, ca.in_proj_weight[512:], c["sup_v"], N * P, 256, 256, bias=ca.in_proj_bias[512:])
-                c["sup_kpm"] = smask.to(torch.uint8).contiguous() if smask is not None else None
-            caches.append(c)
-        ref_all = ops.sigmoid_fwd(self.query_embed.weight.detach().contiguous())            # (seq_len, 2)
-        toks = torch.full((4, N), tok.bos, dtype=torch.int64, device=dev)
-        deltas = torch.tensor([0.0, 1.0, 0.0, 1.0], device=dev).view(4, 1).repeat(1, N).contiguous()
-        unfinished = torch.ones(N, dtype=torch.int32, device=dev)
-        step_t = torch.zeros(1, dtype=torch.int32, device=dev)
-        out_logits = torch.zeros(N, max_len, self.num_classes, device=dev)
-        out_coords = torch.zeros(N, max_len, 2, device=dev)
-        out_hs = torch.zeros(N, max_len, 256, device=dev)
-        alive_after = torch.zeros(max_len, dtype=torch.int32, device=dev)   # #unfinished after each step
-        i, T = 0, max_len
-        while i < max_len:
-            if teacher_stream is not None:
-                toks = torch.stack([teacher_stream[k][:, i] for k in ("seq11", "seq12", "seq21", "seq22")]).contiguous()
-                deltas = torch.stack([teacher_stream[k][:, i] for k in ("delta_x1", "delta_x2", "delta_y1", "delta_y2")]).contiguous()
+                if c["sup_kpm"] is not None:
+                    c["sup_kpm"].copy_(smask.to(torch.uint8))
+        st["vr"].copy_(vr)
+        st["ref_all"].copy_(ops.sigmoid_fwd(self.query_embed.weight.detach().contiguous()))            # (seq_len, 2)
+        toks, deltas, unfinished, step_t = st["toks"], st["deltas"], st["unfinished"], st["step_t"]
+        toks.fill_(tok.bos)
+        deltas.copy_(torch.tensor([0.0, 1.0, 0.0, 1.0], device=dev).view(4, 1).expand(4, N))
+        unfinished.fill_(1)
+        out_logits, out_coords, out_hs, alive_after = st["out_logits"], st["out_coords"], st["out_hs"], st["alive_after"]
+        vr_s, ref_all = st["vr"], st["ref_all"]
+
+        def step_body(i, toks_i, deltas_i):
             ref_i = ref_all[i].view(1, 1, 2).expand(N, 1, 2).contiguous()
-            hs, ref, cls = dec.decode_step(toks, deltas, ref_i, geo, vr, i, caches)
+            hs, ref, cls = dec.decode_step(toks_i, deltas_i, ref_i, geo, vr_s, i, caches)
             out_logits[:, i] = cls; out_coords[:, i] = ref.view(N, 2); out_hs[:, i] = hs.view(N, 256)
             step_t.fill_(i)
             ops.decode_next_tokens(cls, ref.view(N, 2), unfinished, toks, deltas, step_t, N, tok.num_bins, min_len,
                                    tok.eos, tok.sep, tok.pad)
             alive_after[i] = unfinished.sum()
+
+        use_graphs = graph and st["calls"] >= 2            # call 1 of a geometry: eager (also the warm-up the capture needs)
+        i, T = 0, max_len
+        while i < max_len:
+            if teacher_stream is not None:
+                t_i = torch.stack([teacher_stream[k][:, i] for k in ("seq11", "seq12", "seq21", "seq22")]).contiguous()
+                d_i = torch.stack([teacher_stream[k][:, i] for k in ("delta_x1", "delta_x2", "delta_y1", "delta_y2")]).contiguous()
+                step_body(i, t_i, d_i)
+            elif use_graphs:
+                g = st["graphs"].get(i)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    if st["pool"] is None:
+                        st["pool"] = torch.cuda.graph_pool_handle()
+                    with torch.cuda.graph(g, pool=st["pool"]):
+                        step_body(i, toks, deltas)
+                    st["graphs"][i] = g
+                g.replay()
+            else:
+                step_body(i, toks, deltas)
             i += 1
             if teacher_stream is None and (i % sync_every == 0 or i == max_len):
                 alive = alive_after[:i].cpu()
@@ -219,7 +266,8 @@ class RoomFormerV2(nn.Module):
         incomplete = int(unfinished.sum()) if teacher_stream is None else 0
         if incomplete > 0 and os.environ.get("WARN_INCOMPLETE_GENERATION", "1") == "1":
             warnings.warn(f"{incomplete}/{N} sequences reached max_len={max_len} without predicting EOS.")
-        out = {"pred_logits": out_logits[:, :T], "pred_coords": out_coords[:, :T], "gen_out": None}
+        # the state buffers are reused by the next call: hand out copies
+        out = {"pred_logits": out_logits[:, :T].clone(), "pred_coords": out_coords[:, :T].clone(), "gen_out": None}
         if self.room_class_embed is not None:
             hs2 = out_hs[:, :T].contiguous()
             rl = torch.empty(N, T, self.room_class_embed.weight.shape[0], device=dev)

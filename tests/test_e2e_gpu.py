@@ -126,6 +126,17 @@ def test_cached_decode_vs_reference_golden(golden_dir, proc_sd, name):
                                     support_mask=b["support_mask"], skeleton_edges=b["skeleton"])
     assert p["logits"].shape == ref_logits.shape, (p["logits"].shape, ref_logits.shape)
     assert (p["logits"][:, :4].cpu() - ref_logits[:, :4]).abs().max() < 1e-3
+    # hipGraph path: call 1 above was eager, call 2 captures one graph per step while decoding, call 3 replays them;
+    # same kernels in the same order -> bitwise the eager result
+    with torch.no_grad():
+        for _ in range(2):
+            pg = model.forward_inference(samples=b["images"], support_coords=b["support_coords"],
+                                         support_mask=b["support_mask"], skeleton_edges=b["skeleton"], graph=True)
+            assert torch.equal(pg["logits"], p["logits"]) and torch.equal(pg["coordinates"], p["coordinates"])
+        pe = model.forward_inference(samples=b["images"], support_coords=b["support_coords"],
+                                     support_mask=b["support_mask"], skeleton_edges=b["skeleton"], graph=False)
+        assert torch.equal(pe["logits"], p["logits"])
+    assert len(model.base_model._decode_states) == 1 and len(next(iter(model.base_model._decode_states.values()))["graphs"]) >= p["logits"].shape[1]
     top2 = ref_logits.sort(-1).values
     clear = (top2[..., 2] - top2[..., 1]) > 5e-2
     assert torch.equal(p["sequences"].cpu()[clear], t(d["sequences"]).long()[clear])
