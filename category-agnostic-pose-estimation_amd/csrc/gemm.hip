@@ -576,6 +576,59 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny products (M <= 64 rows: the cached decode step multiplies 32 token rows by every weight of the decoder).  A
+// 64x64 MFMA tile would run such a product on N/64 blocks of the 256 CUs with eight serial k-tiles of latency each
+// (10 us measured for 32x256x256); here a block owns SK_COLS output columns, stages the activation rows and its weight
+// rows in LDS (row stride K+4 floats: the 8 rows a wave touches fall on different banks) in chunks of <= 256 k, and every
+// thread carries one (row, column) dot product in plain fp32 FMAs -- exact fp32, no reductions, N/8 blocks.
+// ---------------------------------------------------------------------------------------------
+constexpr int SK_COLS = 8, SK_KC = 256;
+
+__global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) float xs[64 * (SK_KC + 4)];
+  __shared__ __attribute__((aligned(16))) float ws[SK_COLS * (SK_KC + 4)];
+  const int t = threadIdx.x;
+  const int n0 = blockIdx.x * SK_COLS;
+  const int col = t & (SK_COLS - 1), row = t >> 3;                // 512 threads = 64 rows x 8 columns
+  const int LD = SK_KC + 4;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += SK_KC) {
+    const int kc = min(SK_KC, p.K - k0);                          // multiple of 4 (host-checked)
+    const int kq = kc >> 2;
+    if (k0) __syncthreads();
+    for (int i = t; i < p.M * kq; i += 512) {
+      const int r = i / kq, c = (i - r * kq) * 4;
+      *reinterpret_cast<float4*>(&xs[r * LD + c]) = *reinterpret_cast<const float4*>(p.A + (long long)r * p.lda + k0 + c);
+    }
+    for (int i = t; i < SK_COLS * kq; i += 512) {
+      const int r = i / kq, c = (i - r * kq) * 4;
+      const int n = min(n0 + r, p.N - 1);
+      *reinterpret_cast<float4*>(&ws[r * LD + c]) = *reinterpret_cast<const float4*>(p.B + (long long)n * p.ldb + k0 + c);
+    }
+    __syncthreads();
+    if (row < p.M) {
+      const float* xr = &xs[row * LD];
+      const float* wr = &ws[col * LD];
+#pragma unroll 4
+      for (int k = 0; k < kc; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + k);
+        const float4 b = *reinterpret_cast<const float4*>(wr + k);
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+      }
+    }
+  }
+  const int n = n0 + col;
+  if (row < p.M && n < p.N) {
+    float v = acc * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
+    if (p.residual) v += p.residual[(long long)row * p.ldr + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    float* cp = p.C + (long long)row * p.ldc + n;
+    if (p.accumulate) v += *cp;
+    *cp = v;
+  }
+}
+
 template <int BM, int BN>
 int launch_mode(const GemmP& p, int a_mode, int b_mode, bool vec, int prec, dim3 grid, hipStream_t s) {
   const bool kfull = vec && (p.K % BK == 0);
@@ -649,6 +702,17 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   if (d->b_mode == 2 || d->b_mode == 3) vec = vec && (d->N % 4 == 0) && d->N >= 4;
   if ((d->a_mode >= 2 || d->b_mode >= 2) && !vec) return cape_set_error("cape_gemm_f32: conv modes need the aligned vector path");
   CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
+  // skinny products: M <= 64 rows of a dense NT product go to the FMA kernel (exact fp32 in either precision mode)
+  if (d->a_mode == 0 && d->b_mode == 0 && d->M <= 64 && vec && d->split_k == 1 && d->dropout_p == 0.f && !d->colsum_out &&
+      !d->mask_src && (d->N + SK_COLS - 1) / SK_COLS < (1 << 30)) {
+    static const bool off = getenv("CAPE_GEMM_NO_SKINNY") != nullptr;      // tuning switch
+    if (!off) {
+      hipLaunchKernelGGL(gemm_skinny_kernel, dim3((d->N + SK_COLS - 1) / SK_COLS), dim3(512), 0, as_stream(stream), p);
+      CAPE_LAUNCH_CHECK("cape_gemm_f32(skinny)");
+      return 0;
+    }
+  }
+
   // tile choice.  Measured on MI355X (tools/gemm_bench.py): with the 64-cycle fp32 MFMA step the 64x64 tile (4 blocks
   // per CU, 4 waves/SIMD) is never slower than 128x128 and much better balanced on this model's shapes
   // (M = 43520 = 340 x 128 gives 680 big tiles on 512 slots = 1.33 rounds; 2720 small tiles on 1024 slots waste far

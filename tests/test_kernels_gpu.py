@@ -59,6 +59,23 @@ def test_gemm_nt_epilogues(M, N, K):
         close(out3, x @ w.t(), name="split_k")
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (32, 256, 256), (64, 1024, 256), (32, 256, 1024), (7, 3, 36), (33, 70, 516)])
+def test_gemm_skinny_rows(M, N, K):
+    """M <= 64 dense NT products take the exact-fp32 FMA kernel (the cached decode step): epilogues and strided outputs."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, sc = rnd(M, N, seed=4), rnd(N, seed=5).abs() + 0.5
+    xd, wd = x.to(DEV), w.to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(xd, wd, out, M, N, K, bias=b.to(DEV), scale=sc.to(DEV), residual=res.to(DEV), relu=True)
+    close(out, F.relu(x @ w.t() * sc + b + res), tol=2e-6, name="skinny epilogue")
+    big = torch.full((M, 5, N), 7.0, device=DEV)                   # row `2` of a (M, 5, N) cache: ldc = 5 * N
+    ops.gemm(xd, wd, big[:, 2], M, N, K, bias=b.to(DEV), ldc=5 * N)
+    close(big[:, 2], F.linear(x, w, b), tol=2e-6, name="skinny strided out")
+    assert float((big[:, 1] - 7).abs().sum()) == 0 and float((big[:, 3] - 7).abs().sum()) == 0
+    ops.gemm(xd, wd, out, M, N, K, accumulate=True)
+    close(out, F.relu(x @ w.t() * sc + b + res) + x @ w.t(), tol=4e-6, name="skinny accumulate")
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 70), (640, 256, 3), (1000, 1024, 256), (77, 36, 2)])
 def test_gemm_nn_dgrad(M, N, K):
     dy, w = rnd(M, K, seed=1), rnd(K, N, seed=2)
