@@ -16,7 +16,7 @@ def run():
     from cape_amd.models.cape_model import build_cape_model
     from cape_amd.models.train_cape_episodic import get_args_parser
     from cape_amd.hip import lib
-    assert lib.abi_version() == 1
+    assert lib.abi_version() >= 3
     cfg = cape_ref.Cfg()
     sd = procweights.procedural_state_dict()
     args = argparse.ArgumentParser(parents=[get_args_parser()]).parse_args(["--use_geometric_encoder", "--use_gcn_preenc"])
