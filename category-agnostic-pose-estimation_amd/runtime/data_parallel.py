@@ -37,13 +37,19 @@ class EpisodeDataParallel:
             self._install_hooks()
 
     def _broadcast_parameters(self):
+        """Rank 0's model everywhere: the arenas (all trainable tensors) in one message each, then whatever lives outside
+        them -- frozen tensors (stem / layer1 of the backbone), the never-trained tensors of SURVEY fact 5 -- and the buffers."""
+        in_arena = set()
         for a in self.opt.arenas:
             if a.numel:
                 dist.broadcast(a.data, src=0, group=self.pg)
-        for m in (self.model,):
-            for b in m.buffers():
-                if b.is_floating_point():
-                    dist.broadcast(b, src=0, group=self.pg)
+            in_arena.update(id(p) for p in a.params)
+        for p in self.model.parameters():
+            if id(p) not in in_arena:
+                dist.broadcast(p.data, src=0, group=self.pg)
+        for b in self.model.buffers():
+            if b.is_floating_point():
+                dist.broadcast(b, src=0, group=self.pg)
 
     def _build_buckets(self, bucket_elems):
         for a in self.opt.arenas:

@@ -13,6 +13,8 @@ SHAPES = [  # (M, N, K, a_mode, b_mode, split_k)
     (43520, 384, 256, 0, 0, 1), (6400, 256, 256, 0, 0, 1), (6400, 1024, 256, 0, 0, 1), (256, 256, 43520, 1, 1, 64),
     (1024, 256, 43520, 1, 1, 16), (256, 1024, 43520, 1, 1, 16), (256, 256, 6400, 1, 1, 24), (8192, 8192, 1024, 0, 0, 1),
     (4096, 4096, 4096, 0, 0, 1),
+    # M = 256 x 128: one full round of 128x128 tiles at 2 blocks per CU (tile-efficiency comparison without quantisation)
+    (32768, 256, 256, 0, 0, 1), (32768, 1024, 256, 0, 0, 1), (32768, 256, 1024, 0, 0, 1), (32768, 256, 256, 0, 1, 1),
 ]
 
 
