@@ -116,11 +116,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # rehearsal switches (not used by the driver): all ranks on cuda:0 with gloo carrying the CUDA buckets, to exercise the
+    # N > 1 code path on a one-GPU box
+    if os.environ.get("CAPE_BENCH_SAME_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CAPE_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     import cape_amd  # noqa: F401
