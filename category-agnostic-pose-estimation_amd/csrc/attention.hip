@@ -117,6 +117,58 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   }
 }
 
+// Single-query form (the cached decode step: Lq == 1, no dropout): one wave per (image, head).  The general kernel
+// would keep one 4-lane group busy per block walking the keys serially behind a 256-thread staging pass (19 us per call);
+// here the 64 lanes split the keys for q.k (a key row is one 128-byte read per lane), the softmax is two wave
+// reductions, and P.V runs with lane = channel (coalesced V rows), the two half-waves taking alternate keys.
+constexpr int DEC_MAXL = 1024;
+
+__global__ void __launch_bounds__(64) attn_decode_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ V, float* __restrict__ O,
+                                                         float* __restrict__ lse, const AttnP p) {
+  __shared__ float sc[DEC_MAXL];
+  const int h = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const float* qp = Q + (long long)n * p.bsq + h * HD;
+  float q[HD];
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(qp + d);
+    q[d] = a.x * p.scale; q[d + 1] = a.y * p.scale; q[d + 2] = a.z * p.scale; q[d + 3] = a.w * p.scale;
+  }
+  const int jmax = p.mask_mode == 1 ? min(p.Lk, p.causal_offset + 1) : p.Lk;
+  const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
+  const float* kb = K + (long long)n * p.bsk + h * HD;
+  float m = -INFINITY;
+  for (int j = lane; j < jmax; j += 64) {
+    const float* kr = kb + (long long)j * p.ldk;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const float4 b = *reinterpret_cast<const float4*>(kr + d);
+      s += q[d] * b.x + q[d + 1] * b.y + q[d + 2] * b.z + q[d + 3] * b.w;
+    }
+    if (kp && kp[j]) s = -INFINITY;
+    sc[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j < jmax; j += 64) {
+    const float e = __expf(sc[j] - m);             // a fully masked row: m = -inf -> NaN like torch
+    sc[j] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  __syncthreads();                                 // one wave: orders the LDS writes above before the reads below
+  const int c = lane & 31, half = lane >> 5;
+  const float* vb = V + (long long)n * p.bsv + h * HD + c;
+  float acc = 0.f;
+  for (int j = half; j < jmax; j += 2) acc += sc[j] * vb[(long long)j * p.ldv];
+  acc += __shfl_xor(acc, 32, 64);
+  if (lane < 32) O[(long long)n * p.bso + h * HD + c] = acc / l;
+  if (lane == 0) lse[(long long)n * p.H + h] = m + __logf(l);
+}
+
 // dQ: thread group per query row
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
                                                            const float* __restrict__ K, const float* __restrict__ V,
@@ -297,6 +349,11 @@ extern "C" int cape_attn_fwd(const float* Q, const float* K, const float* V, flo
   AttnP p;
   const long long bs[4] = {bsq, bsk, bsv, bso};
   if (fill(p, ldq, ldk, ldv, ldo, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream, true)) return 1;
+  if (Lq == 1 && dropout_p == 0.f && Lk <= DEC_MAXL && H <= 65535 && N <= 65535) {
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(H, N), dim3(64), 0, as_stream(stream), Q, K, V, O, lse, p);
+    CAPE_LAUNCH_CHECK("cape_attn_fwd(decode)");
+    return 0;
+  }
   if (raise_lds_limit()) return 1;
   CAPE_REQUIRE((Lq + ROWS - 1) / ROWS <= 65535 * 32, "cape_attn_fwd: Lq too large");
   const size_t sh = (size_t)2 * (Lk < MAXL ? Lk : MAXL) * HD * sizeof(float);

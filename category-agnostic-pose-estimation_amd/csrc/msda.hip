@@ -260,6 +260,98 @@ __device__ __forceinline__ Tap make_tap(float px, float py, int W, int H, int st
   return t;
 }
 
+// Forward, record form (the training and decode path): same lane layout as msda_fwd_kernel (lane = head*8 + c4), but each
+// lane computes the geometry of its own two samples once and parks {corner ids, aw * bilinear weights} in a wave-private
+// LDS record (weights of taps outside a level are 0, their ids clamped: the walk below is branch-free), and the 8 lanes of
+// a head then walk the 16 records with the gathers of sample j+PF issued before sample j is consumed.  The shuffle form
+// re-derived the geometry in every lane and waited for each sample's four dependent L2 reads in turn (27 us for the 32
+// single-query rows of a decode step, 88 us per encoder layer).
+__global__ void __launch_bounds__(256) msda_fwd_rec_kernel(const float* __restrict__ value, const float* __restrict__ offw,
+                                                            const float* __restrict__ ref, float* __restrict__ out, Levels lv,
+                                                            int N, int S, int Lq, int L, int P, int blocks_per_image) {
+  __shared__ uint2 rec_ids[4][HEADS * 16];
+  __shared__ float4 rec_w[4][HEADS * 16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int n, chunk;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, loc = b >> 3;
+    const int ii = loc / blocks_per_image;
+    chunk = loc - ii * blocks_per_image;
+    n = ii * 8 + xcd;
+    if (n >= N) return;
+  }
+  const int q = chunk * 4 + wv;
+  if (q >= Lq) return;                                           // wave-uniform
+  const int LP = L * P;
+  const int h = lane >> 3, i = lane & 7;
+  const long long qrow = (long long)n * Lq + q;
+  const float* ow = offw + qrow * (HEADS * LP * 3);
+  float px[2], py[2], lg[2];
+  int W[2], H[2], st[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = i + 8 * s;
+    px[s] = 0.f; py[s] = 0.f; lg[s] = -INFINITY; W[s] = 1; H[s] = 1; st[s] = 0;
+    if (j < LP) {
+      const int l = j / P;
+      W[s] = sel4(lv.W, l); H[s] = sel4(lv.H, l); st[s] = sel4(lv.start, l);
+      const float2 rr = *reinterpret_cast<const float2*>(ref + (qrow * L + l) * 2);
+      const float2 oo = *reinterpret_cast<const float2*>(ow + (h * LP + j) * 2);
+      const float Wf = (float)W[s], Hf = (float)H[s];
+      px[s] = (rr.x + oo.x / Wf) * Wf - 0.5f;
+      py[s] = (rr.y + oo.y / Hf) * Hf - 0.5f;
+      lg[s] = ow[HEADS * LP * 2 + h * LP + j];
+    }
+  }
+  const float mx = max8(fmaxf(lg[0], lg[1]));
+  const float e0 = __expf(lg[0] - mx), e1 = __expf(lg[1] - mx);
+  const float inv = 1.f / sum8(e0 + e1);
+  const float aw[2] = {e0 * inv, e1 * inv};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = i + 8 * s;
+    const Tap t = make_tap(px[s], py[s], W[s], H[s], st[s], j < LP, S);
+    const unsigned cl = (unsigned)(S - 1);
+    float4 w = make_float4(aw[s] * (1.f - t.fx) * (1.f - t.fy), aw[s] * t.fx * (1.f - t.fy), aw[s] * (1.f - t.fx) * t.fy,
+                           aw[s] * t.fx * t.fy);
+    if (t.i00 >= (unsigned)S) w.x = 0.f;
+    if (t.i01 >= (unsigned)S) w.y = 0.f;
+    if (t.i10 >= (unsigned)S) w.z = 0.f;
+    if (t.i11 >= (unsigned)S) w.w = 0.f;
+    rec_ids[wv][h * 16 + j] = make_uint2(min(t.i00, cl) | (min(t.i01, cl) << 16), min(t.i10, cl) | (min(t.i11, cl) << 16));
+    rec_w[wv][h * 16 + j] = w;
+  }
+  const float* vb = value + (long long)n * S * CH + h * HD + i * 4;
+  const uint2* rid = &rec_ids[wv][h * 16];
+  const float4* rw = &rec_w[wv][h * 16];
+  constexpr int PF = 4;
+  float4 v[PF + 1][4];
+  auto fetch = [&](int j, int slot) {
+    const uint2 ids = rid[j];                                    // same wave wrote it: ordered by lgkmcnt, no barrier
+    v[slot][0] = *reinterpret_cast<const float4*>(vb + (ids.x & 0xFFFFu) * (unsigned)CH);
+    v[slot][1] = *reinterpret_cast<const float4*>(vb + (ids.x >> 16) * (unsigned)CH);
+    v[slot][2] = *reinterpret_cast<const float4*>(vb + (ids.y & 0xFFFFu) * (unsigned)CH);
+    v[slot][3] = *reinterpret_cast<const float4*>(vb + (ids.y >> 16) * (unsigned)CH);
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < LP) fetch(j, j);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j >= LP) continue;                                       // uniform; the loop stays fully unrolled
+    if (j + PF < LP) fetch(j + PF, (j + PF) % (PF + 1));
+    const int slot = j % (PF + 1);
+    const float4 w = rw[j];
+    acc.x += w.x * v[slot][0].x + w.y * v[slot][1].x + w.z * v[slot][2].x + w.w * v[slot][3].x;
+    acc.y += w.x * v[slot][0].y + w.y * v[slot][1].y + w.z * v[slot][2].y + w.w * v[slot][3].y;
+    acc.z += w.x * v[slot][0].z + w.y * v[slot][1].z + w.z * v[slot][2].z + w.w * v[slot][3].z;
+    acc.w += w.x * v[slot][0].w + w.y * v[slot][1].w + w.z * v[slot][2].w + w.w * v[slot][3].w;
+  }
+  *reinterpret_cast<float4*>(out + qrow * CH + h * HD + i * 4) = acc;
+}
+
 __global__ void __launch_bounds__(256) msda_bwd_offw_kernel(const float* __restrict__ d_out, const float* __restrict__ value,
                                                              const float* __restrict__ offw, const float* __restrict__ ref,
                                                              float* __restrict__ d_offw, float* __restrict__ d_ref, Levels lv,
@@ -493,8 +585,13 @@ extern "C" int cape_msda_fwd(const float* value, const float* offw, const float*
   const int imgs_per_x = (N + 7) / 8;
   const long long blocks = (long long)imgs_per_x * bpi * 8;
   CAPE_REQUIRE(blocks < (1ll << 31), "cape_msda_fwd: grid too large");
-  hipLaunchKernelGGL(msda_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), value, offw, ref, out, lv,
-                     N, S, Lq, L, P, bpi);
+  static const bool shuffle_form = getenv("CAPE_MSDA_FWD_SHUFFLE") != nullptr;      // tuning switch
+  if (S < 65535 && !shuffle_form)
+    hipLaunchKernelGGL(msda_fwd_rec_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), value, offw, ref, out, lv,
+                       N, S, Lq, L, P, bpi);
+  else
+    hipLaunchKernelGGL(msda_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), value, offw, ref, out, lv,
+                       N, S, Lq, L, P, bpi);
   CAPE_LAUNCH_CHECK("cape_msda_fwd");
   return 0;
 }

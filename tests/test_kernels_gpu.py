@@ -426,6 +426,31 @@ def test_attention_fwd_long_sequences(N, Lq, Lk, mode):
     close(O, ref, name="attn fwd long")
 
 
+@pytest.mark.parametrize("N,Lk,mode", [(32, 200, 0), (3, 17, 2), (2, 1, 0), (2, 300, 2), (4, 77, 1)])
+def test_attention_single_query_decode_form(N, Lk, mode):
+    """Lq == 1 takes the one-wave-per-(image, head) kernel: strided K/V caches, key padding, causal offset."""
+    H, cap = 8, Lk + 5
+    q = rnd(N, 1, 256, seed=1)
+    kc, vc = rnd(N, cap, 256, seed=2), rnd(N, cap, 256, seed=3)            # caches longer than the filled part
+    k, v = kc[:, :Lk], vc[:, :Lk]
+    mask, kpm, off, Lk_eff = None, None, 0, Lk
+    if mode == 2:
+        kpm = torch.zeros(N, Lk, dtype=torch.bool)
+        kpm[:, Lk // 2] = True; kpm[0, Lk - 1] = True
+        if Lk > 1:
+            mask = torch.zeros(N, 1, 1, Lk).masked_fill(kpm[:, None, None, :], float("-inf"))
+        else:
+            kpm = None
+    if mode == 1:
+        off = Lk // 2                                                      # query sees keys 0..off
+        mask = torch.zeros(1, Lk).masked_fill(torch.arange(Lk)[None] > off, float("-inf"))
+    ref = _attn_ref(q, k, v, 32 ** -0.5, mask)
+    kpm_d = kpm.to(torch.uint8).to(DEV) if kpm is not None else None
+    O, lse = ops.attn_fwd(q.to(DEV), kc.to(DEV)[:, :Lk], vc.to(DEV)[:, :Lk], N, H, 1, Lk, 32 ** -0.5,
+                          mask_mode=(2 if kpm is not None else (1 if mode == 1 else 0)), causal_offset=off, kpm=kpm_d)
+    close(O, ref, name="attn decode form")
+
+
 def test_gelu_and_scale_residual():
     x, y, g = rnd(37, 256, seed=1, scale=2.0), rnd(37, 256, seed=2), rnd(256, seed=3)
     close(ops.gelu(x.to(DEV)), F.gelu(x), tol=1e-6, name="gelu")

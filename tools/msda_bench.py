@@ -20,6 +20,16 @@ def main():
         offw = torch.cat([off, torch.randn(N, Lq, 128, device="cuda", generator=g)], -1).contiguous()
         ref = torch.rand(N, Lq, 4, 2, device="cuda", generator=g)
         go = torch.randn(N, Lq, 256, device="cuda", generator=g)
+        for _ in range(3):
+            ops.msda_fwd(value, offw, ref, geo, N, Lq)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.msda_fwd(value, offw, ref, geo, N, Lq)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"N={N} Lq={Lq} forward: {e0.elapsed_time(e1) / 20 * 1e3:9.1f} us", flush=True)
         for form in ("atomic", "split"):
             for need_ref in (False,):
                 for _ in range(3):
