@@ -26,9 +26,15 @@ struct AttnP {
   const uint64_t* rng_state; uint32_t rng_stream;
 };
 
+// sum over the 4 lanes of a quad with two DPP quad permutes (xor 1: [1,0,3,2] = 0xB1, xor 2: [2,3,0,1] = 0x4E); the
+// __shfl_xor form compiled to ds_bpermute_b32, an LDS-pipe round trip inside the per-key dependency chain
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float quad_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
   return v;
 }
 
