@@ -719,9 +719,10 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   // less): 43520x256x256 57 -> 77 TF/s, x1024 74 -> 93 TF/s, 4096^3 118 = 118 TF/s.  128x128 stays available for tuning.
   // ... except for deep contractions: with K >= 1024 the 128x128 tile's halved L2 -> L1 traffic per flop wins once there
   // are enough tiles to cover the chip (measured: 43520x256x1024 134 -> 111 us, 1024x256x43520 split 16 118 -> 111 us;
-  // but 256x256x43520 split 64, one 128-tile block per CU: 36 -> 40 us, hence the floor on the output size)
+  // but 256x256x43520 split 64, one 128-tile block per CU: 36 -> 40 us, hence the floor on the output size; and
+  // 1024x256x6400 split 16 (400 deep per split): 27.7 -> 28.9 us, hence the depth is counted per k-split)
   const long long t128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->split_k;
-  bool big = d->K >= 1024 && t128 >= 256 && (long long)d->M * d->N >= 256 * 1024 && d->precision == 1 && vec;
+  bool big = d->K / d->split_k >= 1024 && t128 >= 256 && (long long)d->M * d->N >= 256 * 1024 && d->precision == 1 && vec;
   {
     static const char* force = getenv("CAPE_GEMM_TILE");      // tuning override: 64 or 128
     if (force && force[0] == '1') big = true;

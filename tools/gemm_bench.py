@@ -15,6 +15,7 @@ SHAPES = [  # (M, N, K, a_mode, b_mode, split_k)
     (4096, 4096, 4096, 0, 0, 1),
     # M = 256 x 128: one full round of 128x128 tiles at 2 blocks per CU (tile-efficiency comparison without quantisation)
     (32768, 256, 256, 0, 0, 1), (32768, 1024, 256, 0, 0, 1), (32768, 256, 1024, 0, 0, 1), (32768, 256, 256, 0, 1, 1),
+    (1024, 256, 6400, 1, 1, 16), (256, 1024, 6400, 1, 1, 16), (6400, 256, 1024, 0, 0, 1), (6400, 256, 1024, 0, 1, 1),
 ]
 
 
