@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 GFLOP_PER_EPISODE_256 = 162.9
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
+PEAK_HBM_TBPS = 8.0                # MI355X_MICROARCH.md: HBM3E peak
 
 
 def make_batches(tok, B, K, R, P, n_batches, seed, device):
@@ -245,14 +246,26 @@ def main():
             pass
         # algorithmic bytes per launch: A + B + C once each, fp32 (dense formula; an upper bound for the im2col modes)
         alg_bytes = round(sum(c * 4.0 * (k[0] * k[2] + k[1] * k[2] + k[0] * k[1]) for k, (c, _, _) in r["table"].items()) / max(r["launches"], 1))
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (profiles/r01_gemm_traffic.json)",
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "peak_note": ("bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product (bf16x3 split)"
-                                  if split else "fp32 MFMA dense peak"),
-                    "kernel": "gemm_kernel<BM,BN,AMODE,BMODE> (fp32 MFMA implicit GEMM, all instantiations)",
+        # which roof binds the family: per launch, algorithmic flops / MFMA peak against algorithmic bytes / HBM peak
+        avg_s = r["ms"] * 1e-3 / max(r["launches"], 1)
+        flops_per_launch = r["flops"] / max(r["launches"], 1)
+        t_mfma, t_hbm = flops_per_launch / (peak * 1e12), alg_bytes / (PEAK_HBM_TBPS * 1e12)
+        mfma_view = {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+        hbm_ach = alg_bytes / avg_s / 1e9
+        hbm_view = {"achieved": round(hbm_ach, 1), "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s", "frac": round(hbm_ach / (PEAK_HBM_TBPS * 1e3), 4)}
+        bound = "hbm" if t_hbm >= t_mfma else "mfma"
+        main, other = (hbm_view, mfma_view) if bound == "hbm" else (mfma_view, hbm_view)
+        roofline = {"bound": bound, **main, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (profiles/r01_gemm_traffic.json)",
+                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                    "roof_times_us": {"mfma": round(t_mfma * 1e6, 2), "hbm": round(t_hbm * 1e6, 2)},
+                    "other_roof": {"bound": "mfma" if bound == "hbm" else "hbm", **other},
+                    "peak_note": (("bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product (bf16x3 split)"
+                                   if split else "fp32 MFMA dense peak") + "; HBM3E 8 TB/s"),
+                    "kernel": "gemm_kernel<BM,BN,AMODE,BMODE,VEC,PREC,KFULL> (implicit-GEMM family, all instantiations; "
+                              + ("bf16x3 split on bf16 MFMA" if split else "exact fp32 MFMA") + ")",
                     "launches_per_step": r["launches"] // nprof,
-                    "avg_launch_us": round(r["ms"] * 1e3 / max(r["launches"], 1), 2),
+                    "avg_launch_us": round(avg_s * 1e6, 2),
                     "gemm_ms_per_step": round(r["ms"] / nprof, 2),
                     "gemm_gflop_per_step": round(r["flops"] / nprof / 1e9, 1)}
     elif world > 1 and not a.no_roofline:
