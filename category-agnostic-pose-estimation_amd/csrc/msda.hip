@@ -475,33 +475,35 @@ __global__ void __launch_bounds__(256) msda_bwd_offw_kernel(const float* __restr
   }
 }
 
-constexpr int VC = 8;                                            // channels per block of the value kernel
-#ifndef CAPE_MSDA_VS
-#define CAPE_MSDA_VS 8
-#endif
-constexpr int VS = CAPE_MSDA_VS;                                 // slab row stride in doubles (measured: 9, rows on staggered banks, is 13 % slower than 8)
+// channels per block of the value kernel: 8 while the slab (S+1) x 8 fp64 fits in LDS (S <= ~2100: up to 320x320 images),
+// then 4 (384x384: S = 3060) and 2 (512x512: S = 5440); the slab row stride equals the group width (a padded stride of
+// 9 or 10 doubles measured 10-13 % slower)
 struct ValRec { uint2 ids; float4 w; };                          // 24 bytes: corner ids + aw * bilinear weights
 
+template <int VC>
 __global__ void __launch_bounds__(1024) msda_bwd_value_kernel(const float* __restrict__ d_out, const float* __restrict__ offw,
                                                               const float* __restrict__ ref, float* __restrict__ d_value,
                                                               Levels lv, int N, int S, int Lq, int L, int P) {
+  constexpr int VS = VC, GROUPS = HD / VC, BPI = HEADS * GROUPS;   // slab row stride, channel groups per head, blocks per image
+  constexpr int SLOTS = 64 / VC;                                  // samples a wave advances per step; VC steps cover its 64 records
   extern __shared__ __attribute__((aligned(16))) double slab[];  // [(S + 1)][VS]; row S swallows taps outside a level
   __shared__ uint2 rec_ids[16][64];                              // per wave: [query g (4)][sample j (16)]
   __shared__ float4 rec_w[16][64];
   int n, sub;
   {
-    const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;         // the 32 blocks of an image share an XCD
-    n = (loc >> 5) * 8 + xcd;
-    sub = loc & 31;
+    const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;         // the BPI blocks of an image share an XCD
+    n = (loc / BPI) * 8 + xcd;
+    sub = loc % BPI;
     if (n >= N) return;
   }
-  const int h = sub >> 2, grp = sub & 3;
+  const int h = sub / GROUPS, grp = sub % GROUPS;
   for (int k = threadIdx.x; k < (S + 1) * VS; k += 1024) slab[k] = 0.0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;                        // phase 1: (query, sample)
-  const int c = lane & 7, hb = (lane >> 3) & 1;                  // phase 2: channel c, samples 8*hb .. 8*hb+7 of query g
+  const int c = lane & (VC - 1), slot = lane / VC;               // phase 2: channel c; records slot*VC .. slot*VC+VC-1
+  static_assert(SLOTS * VC == 64 && 16 % VC == 0, "a slot's records must stay inside one query");
   const int LP = L * P;
   const int rowlen = HEADS * LP * 3;
   const int choff = h * HD + grp * VC + c;
@@ -534,10 +536,13 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_kernel(const float* __res
       rec_w[wv][lane] = make_float4(aw * (1.f - t.fx) * (1.f - t.fy), aw * t.fx * (1.f - t.fy), aw * (1.f - t.fx) * t.fy,
                                     aw * t.fx * t.fy);
     }
-    const float go = qlive ? d_out[qrow * CH + choff] : 0.f;
-    const int rbase = (lane & 48) + 8 * hb;
+    // phase 2 lanes read the query of THEIR records (slot*VC >> 4), which is phase 1's g only when VC == 8
+    const int q2 = qb + ((slot * VC) >> 4);
+    const bool q2live = q2 < Lq;
+    const float go = q2live ? d_out[((long long)n * Lq + q2) * CH + choff] : 0.f;
+    const int rbase = slot * VC;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < VC; ++s) {
       const uint2 ids = rec_ids[wv][rbase + s];
       const float4 w = rec_w[wv][rbase + s];
       atomicAdd(&slab[(ids.x & 0xFFFFu) * VS + c], (double)(go * w.x));
@@ -548,10 +553,16 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_kernel(const float* __res
   }
   __syncthreads();
   float* dvb = d_value + (long long)n * S * CH + h * HD + grp * VC;
-  for (int k = threadIdx.x; k < S * 2; k += 1024) {
-    const int p_ = k >> 1, c4 = (k & 1) * 4;
-    const double* sp = &slab[p_ * VS + c4];
-    *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c4) = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
+  if constexpr (VC >= 4) {
+    constexpr int Q = VC / 4;
+    for (int k = threadIdx.x; k < S * Q; k += 1024) {
+      const int p_ = k / Q, c4 = (k % Q) * 4;
+      const double* sp = &slab[p_ * VS + c4];
+      *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c4) = make_float4((float)sp[0], (float)sp[1], (float)sp[2], (float)sp[3]);
+    }
+  } else {
+    for (int k = threadIdx.x; k < S; k += 1024)
+      *reinterpret_cast<float2*>(dvb + (long long)k * CH) = make_float2((float)slab[k * VS], (float)slab[k * VS + 1]);
   }
 }
 
@@ -629,19 +640,26 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
   if (N <= 0 || Lq <= 0) return 0;
   // split form when the (image, head, 8-channel) fp64 slab fits in LDS (S <= ~2300: every image size up to 320x320);
   // larger geometries take the memory-side-atomic form
-  const size_t slab_bytes = (size_t)(S + 1) * VS * sizeof(double);
   const size_t kMaxSlab = 160 * 1024 - 16 * 64 * (sizeof(uint2) + sizeof(float4)) - 512;
+  int vc = 8;                                                    // widest channel group whose slab fits
+  while (vc >= 2 && (size_t)(S + 1) * vc * sizeof(double) > kMaxSlab) vc >>= 1;
+  const size_t slab_bytes = (size_t)(S + 1) * vc * sizeof(double);
   static const bool force_atomic = getenv("CAPE_MSDA_BWD_ATOMIC") != nullptr;      // tuning switch
   const long long imgs8 = ((long long)N + 7) / 8;
   const int bpi = (Lq + 3) / 4;
-  if (force_atomic || slab_bytes > kMaxSlab || S >= 65535 || imgs8 * 8 * 32 >= (1ll << 31) || imgs8 * 8 * bpi >= (1ll << 31))
+  const long long vblocks = imgs8 * 8 * HEADS * (HD / (vc < 2 ? 2 : vc));
+  if (force_atomic || vc < 2 || S >= 65535 || vblocks >= (1ll << 31) || imgs8 * 8 * bpi >= (1ll << 31))
     return cape_msda_bwd_atomic(d_out, value, offw, ref, shapes, level_start, d_value, d_offw, d_ref, N, S, Lq, L, P, stream);
   Levels lv;
   if (fill_levels(lv, shapes, level_start, L, S)) return 1;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_kernel<8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_kernel<4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_kernel<2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
     if (e != hipSuccess) return cape_set_error("cape_msda_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
@@ -649,8 +667,11 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
     hipError_t e = hipMemsetAsync(d_ref, 0, sizeof(float) * (size_t)N * Lq * L * 2, as_stream(stream));
     if (e != hipSuccess) return cape_set_error("cape_msda_bwd: memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(msda_bwd_value_kernel, dim3((unsigned)(imgs8 * 8 * 32)), dim3(1024), slab_bytes, as_stream(stream), d_out,
-                     offw, ref, d_value, lv, N, S, Lq, L, P);
+#define VALUE_LAUNCH(W)                                                                                                     \
+  hipLaunchKernelGGL((msda_bwd_value_kernel<W>), dim3((unsigned)vblocks), dim3(1024), slab_bytes, as_stream(stream), d_out, offw, \
+                     ref, d_value, lv, N, S, Lq, L, P)
+  if (vc == 8) VALUE_LAUNCH(8); else if (vc == 4) VALUE_LAUNCH(4); else VALUE_LAUNCH(2);
+#undef VALUE_LAUNCH
   hipLaunchKernelGGL(msda_bwd_offw_kernel, dim3((unsigned)(imgs8 * 8 * bpi)), dim3(256), 0, as_stream(stream), d_out, value, offw,
                      ref, d_offw, d_ref, lv, N, S, Lq, L, P, bpi);
   CAPE_LAUNCH_CHECK("cape_msda_bwd");

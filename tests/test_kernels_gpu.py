@@ -328,7 +328,9 @@ def _msda_ref(value, offw, ref, shapes):
 
 @pytest.mark.parametrize("N,Lq,shapes", [(2, 37, [(8, 8), (4, 4), (2, 2), (1, 1)]), (9, 5, [(6, 10), (3, 5), (2, 3), (1, 2)]),
                                          (1, 1360, [(32, 32), (16, 16), (8, 8), (4, 4)]),
-                                         (3, 70, [(32, 32), (16, 16), (8, 8), (4, 4)])])
+                                         (3, 70, [(32, 32), (16, 16), (8, 8), (4, 4)]),
+                                         (2, 90, [(48, 48), (24, 24), (12, 12), (6, 6)]),      # S = 3060: 4-channel slabs
+                                         (1, 130, [(64, 64), (32, 32), (16, 16), (8, 8)])])    # S = 5440: 2-channel slabs
 @pytest.mark.parametrize("form", ["split", "atomic"])
 def test_msda_fwd_bwd(N, Lq, shapes, form):
     value, offw, ref = _msda_inputs(N, Lq, shapes, 11)

@@ -12,8 +12,10 @@ SHAPES = [(32, 32), (16, 16), (8, 8), (4, 4)]
 
 
 def main():
-    geo = ops.LevelGeometry(SHAPES)
-    for N, Lq in ((32, 1360), (32, 40), (8, 1360)):
+    R = int(os.environ.get("IMAGE", "256"))
+    shapes = [(R // 8, R // 8), (R // 16, R // 16), (R // 32, R // 32), (R // 64, R // 64)]
+    geo = ops.LevelGeometry(shapes)
+    for N, Lq in ((32, geo.S), (32, 40), (8, geo.S)):
         g = torch.Generator(device="cuda").manual_seed(0)
         value = torch.randn(N, geo.S, 256, device="cuda", generator=g)
         off = torch.randn(N, Lq, 256, device="cuda", generator=g) * float(os.environ.get("OFF_SCALE", "1.5"))
