@@ -15,7 +15,16 @@ from . import lib
 _F32 = torch.float32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  The two private C entry points cost ~0.5 us; the public
+    torch.cuda.current_stream().cuda_stream walks Python helpers for ~8 us -- 40 % of a launcher's host time, ~6 ms per
+    training step (1250 launches)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
