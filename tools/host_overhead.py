@@ -22,3 +22,16 @@ import cProfile,pstats
 pr=cProfile.Profile(); pr.enable()
 for _ in range(2000): ops.gemm(x,w,y,64,256,256,bias=b)
 pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(12)
+from cape_amd.runtime.arena import ParamGroupArena  # noqa
+lin = torch.nn.Linear(256, 256).cuda()
+from cape_amd.runtime.optimizer import ArenaAdamW
+class M(torch.nn.Module):
+    def __init__(s):
+        super().__init__(); s.l = lin
+opt = ArenaAdamW(M().cuda(), lr=1e-4, lr_backbone=1e-5)
+def fb2():
+    o = HF.linear(xr, lin.weight, lin.bias); o.backward(x)
+print("HF.linear fwd+bwd (arena, side stream) %.1f us" % t(fb2, 500))
+pr=cProfile.Profile(); pr.enable()
+for _ in range(500): fb2()
+pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(22)
