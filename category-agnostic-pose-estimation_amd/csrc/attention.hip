@@ -311,6 +311,67 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core form of the attention core for long sequences (the decoder's 200 x 200 causal self-attention): the two
+// contractions Q K^T and P V (and the four of the backward) run as batched launches of the GEMM family (one product per
+// (image, head), bf16x3 or exact fp32 MFMA), and only the row softmax stays here: one wave per score row.
+//   forward : P = softmax(scale * S + mask) ; Pd = dropout(P)            (S, P, Pd: (N, H, Lq, Lk) fp32)
+//   backward: dS = scale * P o (dPd_eff - sum_j dPd_eff P)  with dPd_eff = dropout-mask o dPd / keep      (in place)
+// The dropout decision uses the same counter-based index ((n*H + h)*Lq + i)*Lk + j as the fused kernels above.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
+                                                               float* __restrict__ Pd, const AttnP p) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (n*H + h)*Lq + i
+  const long long rows = (long long)p.N * p.H * p.Lq;
+  if (row >= rows) return;                                                   // wave-uniform
+  const int lane = threadIdx.x & 63;
+  const int i = (int)(row % p.Lq);
+  const int n = (int)(row / ((long long)p.H * p.Lq));
+  const float* s = S + row * p.Lk;
+  const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
+  const int jend = p.mask_mode == 1 ? min(p.Lk, i + p.causal_offset + 1) : p.Lk;
+  float m = -INFINITY;
+  for (int j = lane; j < jend; j += 64)
+    if (!(kp && kp[j])) m = fmaxf(m, s[j] * p.scale);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j < jend; j += 64)
+    if (!(kp && kp[j])) l += __expf(s[j] * p.scale - m);
+  l = wave_sum(l);
+  const float inv = 1.f / l;                                                 // fully masked row: 0/0 -> NaN like torch
+  uint64_t seed = 0, step = 0;
+  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  for (int j = lane; j < p.Lk; j += 64) {
+    const bool live = j < jend && !(kp && kp[j]);
+    const float pv = live ? __expf(s[j] * p.scale - m) * inv : (l == 0.f ? NAN : 0.f);
+    P[row * p.Lk + j] = pv;
+    if (Pd) Pd[row * p.Lk + j] = cape_keep(seed, step, p.rng_stream, (uint64_t)row * p.Lk + j, p.thresh) ? pv * p.inv_keep : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dS, const AttnP p) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long rows = (long long)p.N * p.H * p.Lq;
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  uint64_t seed = 0, step = 0;
+  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  const float* pr = P + row * p.Lk;
+  float* d = dS + row * p.Lk;
+  float t = 0.f;
+  for (int j = lane; j < p.Lk; j += 64) {
+    float g = d[j];
+    if (p.thresh) g = cape_keep(seed, step, p.rng_stream, (uint64_t)row * p.Lk + j, p.thresh) ? g * p.inv_keep : 0.f;
+    t += g * pr[j];
+  }
+  t = wave_sum(t);
+  for (int j = lane; j < p.Lk; j += 64) {
+    float g = d[j];
+    if (p.thresh) g = cape_keep(seed, step, p.rng_stream, (uint64_t)row * p.Lk + j, p.thresh) ? g * p.inv_keep : 0.f;
+    d[j] = p.scale * pr[j] * (g - t);
+  }
+}
+
 int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, const long long* bs, int N, int H, int Lq, int Lk, float scale,
          int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
          uint32_t rng_stream, bool fwd = false) {
@@ -386,5 +447,35 @@ extern "C" int cape_attn_bwd(const float* dO, const float* Q, const float* K, co
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + ROWS - 1) / ROWS, H, N), dim3(256), sh2, as_stream(stream), dO, Q, K, V,
                      O, lse, dK, dV, p);
   CAPE_LAUNCH_CHECK("cape_attn_bwd");
+  return 0;
+}
+
+extern "C" int cape_attn_softmax_fwd(const float* S, float* P, float* Pd, int N, int H, int Lq, int Lk, float scale, int mask_mode,
+                                     int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
+                                     uint32_t rng_stream, cape_stream_t stream) {
+  CAPE_REQUIRE(S && P, "cape_attn_softmax_fwd: null pointer");
+  CAPE_REQUIRE((dropout_p > 0.f) == (Pd != nullptr), "cape_attn_softmax_fwd: Pd goes with dropout");
+  if (N <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  AttnP p;
+  const long long bs[4] = {0, 0, 0, 0};
+  if (fill(p, 4, 4, 4, 4, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream, true)) return 1;
+  const long long rows = (long long)N * H * Lq;
+  CAPE_REQUIRE((rows + 3) / 4 < (1ll << 31), "cape_attn_softmax_fwd: too many rows");
+  hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), S, P, Pd, p);
+  CAPE_LAUNCH_CHECK("cape_attn_softmax_fwd");
+  return 0;
+}
+
+extern "C" int cape_attn_softmax_bwd(const float* P, float* dS, int N, int H, int Lq, int Lk, float scale, float dropout_p,
+                                     const uint64_t* rng_state, uint32_t rng_stream, cape_stream_t stream) {
+  CAPE_REQUIRE(P && dS, "cape_attn_softmax_bwd: null pointer");
+  if (N <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  AttnP p;
+  const long long bs[4] = {0, 0, 0, 0};
+  if (fill(p, 4, 4, 4, 4, bs, N, H, Lq, Lk, scale, 0, 0, nullptr, dropout_p, rng_state, rng_stream, true)) return 1;
+  const long long rows = (long long)N * H * Lq;
+  CAPE_REQUIRE((rows + 3) / 4 < (1ll << 31), "cape_attn_softmax_bwd: too many rows");
+  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), P, dS, p);
+  CAPE_LAUNCH_CHECK("cape_attn_softmax_bwd");
   return 0;
 }

@@ -32,7 +32,14 @@ __device__ __forceinline__ float4 ldg4(const float* p, int valid) {
 
 // KFULL (host-checked: K % 32 == 0): no k-tail handling at all in the loads
 template <int BM, int BN, int AMODE, int BMODE, bool VEC, int PREC, bool KFULL>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmP p) {
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmP pin) {
+  GemmP p = pin;
+  if (gridDim.y > 1) {                                             // batched launch: uniform operand offsets
+    const int b0 = blockIdx.y / p.bdiv, b1 = blockIdx.y - b0 * p.bdiv;
+    p.A += b0 * p.sA0 + b1 * p.sA1;
+    p.B += b0 * p.sB0 + b1 * p.sB1;
+    p.C += b0 * p.sC0 + b1 * p.sC1;
+  }
   constexpr bool A_KC = (AMODE == 0 || AMODE == 2 || AMODE == 3);
   constexpr bool B_KC = (BMODE == 0);
   constexpr int A_LD = A_KC ? 36 : (BM + 4);
@@ -687,10 +694,16 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
 
   p.Bhi = d->B_hi; p.Blo = d->B_lo; p.ldp = d->ldp;
   p.mask_src = d->mask_src; p.ldm = d->ldm; p.mask_scale = d->mask_scale;
+  p.bdiv = d->batch_div > 0 ? d->batch_div : 1;
+  p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
+  if (d->batch > 1)
+    CAPE_REQUIRE(d->batch <= 65535 && d->split_k == 1 && !d->bias && !d->scale && !d->residual && !d->mask_src && !d->colsum_out &&
+                     d->dropout_p == 0.f && (d->a_mode == 0 || d->a_mode == 1) && (d->b_mode == 0 || d->b_mode == 1),
+                 "cape_gemm_f32: batched launches take dense modes, no epilogue vectors, split_k 1, batch <= 65535");
   if (d->mask_src) CAPE_REQUIRE(d->split_k == 1, "cape_gemm_f32: mask_src needs split_k == 1");
   if (d->B_hi || d->B_lo) CAPE_REQUIRE(d->B_hi && d->B_lo && d->ldp >= d->K, "cape_gemm_f32: B planes need both pointers and ldp >= K");
   // weight-stationary kernel when the B operand comes with pre-split planes (see gemm_ws.hip); same epilogue semantics
-  if (d->precision == 1 && cape_gemm_ws_eligible(p, d->a_mode)) return cape_gemm_ws_launch(p, d->a_mode, as_stream(stream));
+  if (d->precision == 1 && d->batch <= 1 && cape_gemm_ws_eligible(p, d->a_mode)) return cape_gemm_ws_launch(p, d->a_mode, as_stream(stream));
 
   // vector path: every 16-byte load must be aligned and stay inside its row
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -700,10 +713,11 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   if (d->b_mode == 0) vec = vec && (d->ldb % 4 == 0) && (d->K % 4 == 0);
   if (d->b_mode == 1) vec = vec && (d->ldb % 4 == 0) && (d->N % 4 == 0) && d->N >= 4;
   if (d->b_mode == 2 || d->b_mode == 3) vec = vec && (d->N % 4 == 0) && d->N >= 4;
+  if (d->batch > 1) vec = vec && ((d->sA0 | d->sA1 | d->sB0 | d->sB1) % 4 == 0);
   if ((d->a_mode >= 2 || d->b_mode >= 2) && !vec) return cape_set_error("cape_gemm_f32: conv modes need the aligned vector path");
   CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
   // skinny products: M <= 64 rows of a dense NT product go to the FMA kernel (exact fp32 in either precision mode)
-  if (d->a_mode == 0 && d->b_mode == 0 && d->M <= 64 && vec && d->split_k == 1 && d->dropout_p == 0.f && !d->colsum_out &&
+  if (d->a_mode == 0 && d->b_mode == 0 && d->M <= 64 && d->batch <= 1 && vec && d->split_k == 1 && d->dropout_p == 0.f && !d->colsum_out &&
       !d->mask_src && (d->N + SK_COLS - 1) / SK_COLS < (1 << 30)) {
     static const bool off = getenv("CAPE_GEMM_NO_SKINNY") != nullptr;      // tuning switch
     if (!off) {
@@ -734,7 +748,7 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   CAPE_REQUIRE(ntiles < (1ll << 31), "cape_gemm_f32: too many tiles");
   CAPE_REQUIRE(ntiles * d->split_k < (1ll << 31), "cape_gemm_f32: grid too large");
-  dim3 grid((unsigned)(ntiles * d->split_k));
+  dim3 grid((unsigned)(ntiles * d->split_k), (unsigned)(d->batch > 1 ? d->batch : 1));
   int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream))
                : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream));
   if (rc) return rc;

@@ -49,6 +49,8 @@ struct GemmP {
   const unsigned short* Bhi; const unsigned short* Blo; long long ldp;
   // optional gate of the result: v = mask_src[m][n] != 0 ? v * mask_scale : 0 (backward of a fused relu/dropout)
   const float* mask_src; long long ldm; float mask_scale;
+  // batched launch (grid.y = batch): batch b = b0 * bdiv + b1 offsets the operands by b0 * s?0 + b1 * s?1 elements
+  int bdiv; long long sA0, sA1, sB0, sB1, sC0, sC1;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

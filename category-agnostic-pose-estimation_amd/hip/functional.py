@@ -587,19 +587,26 @@ class MHAFn(torch.autograd.Function):
         ops.gemm(v_in.view(-1, C), in_w[2 * C:], v, N * Lk, C, C, bias=in_b[2 * C:])
         scale = (C // nheads) ** -0.5
         rng = Runtime.get_rng(dev) if dropout_p > 0 else None
-        O, lse = ops.attn_fwd(q, k, v, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm_u8, dropout_p=dropout_p,
-                              rng=rng, rng_stream=rng_stream)
+        mm = ops.attn_mm_ok(N, nheads, Lq, Lk)      # long rows: contractions on the matrix cores, softmax kernel in between
+        if mm:
+            O, Pp, Pu = ops.attn_mm_fwd(q, k, v, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm_u8, dropout_p=dropout_p,
+                                        rng=rng, rng_stream=rng_stream)
+            lse = Pp
+            ctx.Pu = Pu
+        else:
+            O, lse = ops.attn_fwd(q, k, v, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm_u8, dropout_p=dropout_p,
+                                  rng=rng, rng_stream=rng_stream)
         out = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
         ops.gemm(O.view(-1, C), out_w, out, N * Lq, C, C, bias=out_b)
         ctx.save_for_backward(q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm_u8)
         ctx.refs = (in_w, in_b, out_w, out_b)
-        ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in)
+        ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in, mm)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm = ctx.saved_tensors
-        nheads, mask_mode, p, stream, scale, kv_same, qk_same = ctx.meta
+        nheads, mask_mode, p, stream, scale, kv_same, qk_same, mm = ctx.meta
         N, Lq, C = q_in.shape
         Lk = k_in.shape[1]
         dev = d_out.device
@@ -625,8 +632,12 @@ class MHAFn(torch.autograd.Function):
             out_grads()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         rng = Runtime.get_rng(dev) if p > 0 else None
-        ops.attn_bwd(dO.view(N, Lq, C), q, k, v, O, lse, dq, dk, dv, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm,
-                     dropout_p=p, rng=rng, rng_stream=stream)
+        if mm:
+            ops.attn_mm_bwd(dO.view(N, Lq, C), q, k, v, lse, ctx.Pu, dq, dk, dv, N, nheads, Lq, Lk, scale, dropout_p=p, rng=rng,
+                            rng_stream=stream)
+        else:
+            ops.attn_bwd(dO.view(N, Lq, C), q, k, v, O, lse, dq, dk, dv, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm,
+                         dropout_p=p, rng=rng, rng_stream=stream)
 
         def in_grads():
             for i, (g, src, M) in enumerate(((dq, q_in, Mq), (dk, k_in, Mk), (dv, v_in, Mk))):

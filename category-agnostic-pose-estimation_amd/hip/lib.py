@@ -42,6 +42,8 @@ class GemmDesc(ctypes.Structure):
         ("rng_state", c_void_p), ("rng_stream", c_uint32), ("colsum_out", c_void_p), ("precision", c_int),
         ("B_hi", c_void_p), ("B_lo", c_void_p), ("ldp", c_longlong),
         ("mask_src", c_void_p), ("ldm", c_longlong), ("mask_scale", c_float),
+        ("batch", c_int), ("batch_div", c_int), ("sA0", c_longlong), ("sA1", c_longlong), ("sB0", c_longlong), ("sB1", c_longlong),
+        ("sC0", c_longlong), ("sC1", c_longlong),
     ]
 
 
@@ -60,6 +62,8 @@ _SIGS = {
     "cape_msda_bwd_atomic": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_bwd": [P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
+    "cape_attn_softmax_fwd": [P, P, P, I, I, I, I, F, I, I, P, F, P, U32, P],
+    "cape_attn_softmax_bwd": [P, P, I, I, I, I, F, F, P, U32, P],
     "cape_add_f32": [P, P, P, LL, P],
     "cape_gelu_f32": [P, P, LL, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],

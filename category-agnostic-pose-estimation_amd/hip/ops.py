@@ -141,7 +141,7 @@ def split_planes(W, O, T, C, want_plain=True, want_transposed=True):
 
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None,
-         colsum_out=None, planes=None, mask_src=None, mask_scale=1.0):
+         colsum_out=None, planes=None, mask_src=None, mask_scale=1.0, batch=None):
     """planes = (hi, lo, ldp): the B operand pre-split into bf16 planes [N][K] (split_planes); optional."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
         _chk(t, "gemm." + n, contiguous=False)
@@ -175,17 +175,27 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         _chk(colsum_out, "gemm.colsum_out", contiguous=False)
         assert a_mode == 1 and _avail(colsum_out) >= M       # fused bias gradient of the wgrad product
         d.colsum_out = colsum_out.data_ptr()
+    if batch is not None:
+        # (count, div, sA0, sA1, sB0, sB1, sC0, sC1): batch b = b0 * div + b1 offsets A/B/C by b0 * s?0 + b1 * s?1 elements
+        cnt, div, sA0, sA1, sB0, sB1, sC0, sC1 = batch
+        assert cnt >= 1 and div >= 1 and cnt % div == 0
+        d.batch, d.batch_div = cnt, div
+        d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = sA0, sA1, sB0, sB1, sC0, sC1
+        last0, last1 = cnt // div - 1, div - 1
+        offA, offB, offC = last0 * sA0 + last1 * sA1, last0 * sB0 + last1 * sB1, last0 * sC0 + last1 * sC1
+    else:
+        offA = offB = offC = 0
     # host-side extent checks (dense modes)
     if a_mode == 0 and M > 0:
-        assert _avail(A) >= (M - 1) * d.lda + K, "gemm: A too small"
+        assert _avail(A) >= offA + (M - 1) * d.lda + K, "gemm: A too small"
     if a_mode == 1 and K > 0:
-        assert _avail(A) >= (K - 1) * d.lda + M, "gemm: A^T too small"
+        assert _avail(A) >= offA + (K - 1) * d.lda + M, "gemm: A^T too small"
     if b_mode == 0 and N > 0:
-        assert _avail(B) >= (N - 1) * d.ldb + K, "gemm: B too small"
+        assert _avail(B) >= offB + (N - 1) * d.ldb + K, "gemm: B too small"
     if b_mode == 1 and K > 0:
-        assert _avail(B) >= (K - 1) * d.ldb + N, "gemm: B too small"
+        assert _avail(B) >= offB + (K - 1) * d.ldb + N, "gemm: B too small"
     if M > 0:
-        assert _avail(C) >= (M - 1) * d.ldc + N, "gemm: C too small"
+        assert _avail(C) >= offC + (M - 1) * d.ldc + N, "gemm: C too small"
     if residual is not None:
         assert _avail(residual) >= (M - 1) * d.ldr + N, "gemm: residual too small"
     if bias is not None:
@@ -339,6 +349,45 @@ def attn_fwd(Q, K, V, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=Non
              float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
              rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
     return O, lse
+
+
+def attn_mm_ok(N, H, Lq, Lk):
+    """The matrix-core attention form (batched GEMMs + row softmax) pays off for long rows and needs aligned shapes."""
+    return (os.environ.get("CAPE_ATTN_MM", "1") == "1" and Lq >= 64 and Lk >= 64 and Lq % 4 == 0 and Lk % 4 == 0 and N * H <= 65535)
+
+
+def attn_mm_fwd(Q, K, V, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0, rng=None, rng_stream=0):
+    """Q K^T and P V as one batched GEMM launch each (a product per (image, head)), row softmax in between.
+    Returns O (N, Lq, H*32) and the saved probabilities (P, Pd) for attn_mm_bwd (Pd is P when there is no dropout)."""
+    dev = Q.device
+    S = torch.empty(N, H, Lq, Lk, dtype=_F32, device=dev)
+    gemm(Q, K, S, Lq, Lk, 32, lda=_ld(Q), ldb=_ld(K), ldc=Lk,
+         batch=(N * H, H, Q.stride(0), 32, K.stride(0), 32, H * Lq * Lk, Lq * Lk))
+    P = torch.empty_like(S)
+    Pd = torch.empty_like(S) if dropout_p > 0 else None
+    lib.call("cape_attn_softmax_fwd", _p(S), _p(P), _p(Pd), N, H, Lq, Lk, float(scale), mask_mode, causal_offset, _p(kpm),
+             float(dropout_p), rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+    Pu = Pd if Pd is not None else P
+    O = torch.empty(N, Lq, H * 32, dtype=_F32, device=dev)
+    gemm(Pu, V, O, Lq, 32, Lk, a_mode=0, b_mode=1, lda=Lk, ldb=_ld(V), ldc=H * 32,
+         batch=(N * H, H, H * Lq * Lk, Lq * Lk, V.stride(0), 32, Lq * H * 32, 32))
+    return O, P, Pu
+
+
+def attn_mm_bwd(dO, Q, K, V, P, Pu, dQ, dK, dV, N, H, Lq, Lk, scale, dropout_p=0.0, rng=None, rng_stream=0):
+    """dV = Pd^T dO ; dPd = dO V^T ; dS = softmax-backward (in place) ; dQ = dS K ; dK = dS^T Q  (batched GEMMs)."""
+    blk, img = Lq * Lk, H * Lq * Lk
+    gemm(Pu, dO, dV, Lk, 32, Lq, a_mode=1, b_mode=1, lda=Lk, ldb=H * 32, ldc=_ld(dV),
+         batch=(N * H, H, img, blk, Lq * H * 32, 32, dV.stride(0), 32))
+    dS = torch.empty(N, H, Lq, Lk, dtype=_F32, device=dO.device)
+    gemm(dO, V, dS, Lq, Lk, 32, lda=H * 32, ldb=_ld(V), ldc=Lk,
+         batch=(N * H, H, Lq * H * 32, 32, V.stride(0), 32, img, blk))
+    lib.call("cape_attn_softmax_bwd", _p(P), _p(dS), N, H, Lq, Lk, float(scale), float(dropout_p),
+             rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+    gemm(dS, K, dQ, Lq, 32, Lk, a_mode=0, b_mode=1, lda=Lk, ldb=_ld(K), ldc=_ld(dQ),
+         batch=(N * H, H, img, blk, K.stride(0), 32, dQ.stride(0), 32))
+    gemm(dS, Q, dK, Lk, 32, Lq, a_mode=1, b_mode=1, lda=Lk, ldb=_ld(Q), ldc=_ld(dK),
+         batch=(N * H, H, img, blk, Q.stride(0), 32, dK.stride(0), 32))
 
 
 def attn_bwd(dO, Q, K, V, O, lse, dQ, dK, dV, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0,

@@ -86,6 +86,10 @@ typedef struct {
      mask_src = the saved output of a fused linear+ReLU(+dropout p) and mask_scale = 1/(1-p), the dgrad of the *next*
      layer emits the pre-activation gradient directly (FFN backward without a separate relu/dropout-backward pass). */
   const float* mask_src; long long ldm; float mask_scale;
+  /* optional batched launch (dense modes, no epilogue vectors, split_k 1): `batch` products in one launch, batch index
+     b = b0 * batch_div + b1 offsets A / B / C by b0 * s?0 + b1 * s?1 elements -- e.g. the per-(image, head) Q K^T and P V
+     products of attention with heads interleaved in the rows (b0 = image, b1 = head, s?1 = 32). batch <= 1 = single product. */
+  int batch, batch_div; long long sA0, sA1, sB0, sB1, sC0, sC1;
 } cape_gemm_desc;
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
@@ -182,6 +186,16 @@ int cape_attn_bwd(const float* dO, const float* Q, const float* K, const float* 
                   int N, int H, int Lq, int Lk, float scale, int mask_mode, int causal_offset,
                   const uint8_t* kpm, float dropout_p, const uint64_t* rng_state, uint32_t rng_stream,
                   cape_stream_t stream);
+/* Row softmax of the matrix-core attention form: the contractions Q K^T / P V (and dV, dP, dQ, dK) are batched
+ * cape_gemm_f32 launches, one product per (image, head); S, P, Pd, dS are (N, H, Lq, Lk) fp32, masks and the dropout
+ * stream indexed exactly as in cape_attn_fwd/bwd.  fwd: P = softmax(scale*S + mask), Pd = dropout(P) (Pd NULL iff p = 0);
+ * bwd (in place on dS, which holds dPd on entry): dS = scale * P o (g - sum_j g P), g = dropout-mask o dPd / keep. */
+int cape_attn_softmax_fwd(const float* S, float* P, float* Pd, int N, int H, int Lq, int Lk, float scale, int mask_mode,
+                          int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
+                          uint32_t rng_stream, cape_stream_t stream);
+int cape_attn_softmax_bwd(const float* P, float* dS, int N, int H, int Lq, int Lk, float scale, float dropout_p,
+                          const uint64_t* rng_state, uint32_t rng_stream, cape_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / small ops.  `dim_t` = device float[128] temperature table

@@ -460,6 +460,65 @@ def test_gelu_and_scale_residual():
     close(ops.scale_residual(x.to(DEV), y.to(DEV)), x + y, tol=1e-6, name="residual")
 
 
+@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 72, 128, 2), (1, 64, 260, 0)])
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+def test_attention_matrix_core_form(N, Lq, Lk, mode, prec):
+    """Batched-GEMM attention (Q K^T, P V, dV, dP, dQ, dK on the matrix cores + row softmax kernels) against torch autograd,
+    on strided head-interleaved views like the fused kernels."""
+    H = 8
+    big_q, big_k, big_v = rnd(N, Lq, 768, seed=1), rnd(N, Lk, 768, seed=2), rnd(N, Lk, 768, seed=3)
+    q, k, v = big_q[..., :256], big_k[..., 256:512], big_v[..., 512:]
+    qc, kc, vc = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+    mask, kpm = None, None
+    if mode == 1:
+        mask = torch.triu(torch.full((Lq, Lk), float("-inf")), diagonal=1)
+    if mode == 2:
+        kpm = torch.zeros(N, Lk, dtype=torch.bool)
+        kpm[:, 3] = True; kpm[0, 100:] = True
+        mask = torch.zeros(N, 1, 1, Lk).masked_fill(kpm[:, None, None, :], float("-inf"))
+    scale = 32 ** -0.5
+    ref = _attn_ref(qc, kc, vc, scale, mask)
+    go = rnd(N, Lq, 256, seed=4)
+    ref.backward(go)
+    Qd, Kd, Vd = big_q.to(DEV), big_k.to(DEV), big_v.to(DEV)
+    qd, kd, vd = Qd[..., :256], Kd[..., 256:512], Vd[..., 512:]
+    kpm_d = kpm.to(torch.uint8).to(DEV) if kpm is not None else None
+    old = ops.get_gemm_precision()
+    try:
+        ops.set_gemm_precision(prec)
+        assert ops.attn_mm_ok(N, H, Lq, Lk)
+        O, P, Pu = ops.attn_mm_fwd(qd, kd, vd, N, H, Lq, Lk, scale, mask_mode=mode, kpm=kpm_d)
+        dQ, dK, dV = torch.zeros_like(Qd), torch.zeros_like(Kd), torch.zeros_like(Vd)
+        ops.attn_mm_bwd(go.to(DEV), qd, kd, vd, P, Pu, dQ[..., :256], dK[..., 256:512], dV[..., 512:], N, H, Lq, Lk, scale)
+    finally:
+        ops.set_gemm_precision(old)
+    tol = 1e-4 if prec == "f32" else 3e-4
+    close(O, ref, tol=tol, name="attn mm fwd")
+    close(dQ[..., :256], qc.grad, tol=2 * tol, name="attn mm dQ")
+    close(dK[..., 256:512], kc.grad, tol=2 * tol, name="attn mm dK")
+    close(dV[..., 512:], vc.grad, tol=2 * tol, name="attn mm dV")
+    assert float(dQ[..., 256:].abs().sum()) == 0
+    # same probabilities as the fused kernel (same masks)
+    O2, _ = ops.attn_fwd(qd, kd, vd, N, H, Lq, Lk, scale, mask_mode=mode, kpm=kpm_d)
+    close(O, O2.cpu(), tol=tol, name="attn mm vs fused")
+
+
+def test_attention_matrix_core_form_dropout_consistent():
+    """Dropout: same keep decisions as the fused kernel (same counter index), and the gradient of its own forward."""
+    N, H, L = 2, 8, 128
+    q, k, v = rnd(N, L, 256, seed=1).to(DEV), rnd(N, L, 256, seed=2).to(DEV), rnd(N, L, 256, seed=3).to(DEV)
+    g = rnd(N, L, 256, seed=4).to(DEV)
+    rng = ops.RngState(99, DEV)
+    O, P, Pu = ops.attn_mm_fwd(q, k, v, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    Of, _ = ops.attn_fwd(q, k, v, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    close(O, Of.cpu(), tol=3e-4, name="attn mm dropout vs fused")
+    dQ, dK, dV = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attn_mm_bwd(g, q, k, v, P, Pu, dQ, dK, dV, N, H, L, L, 0.2, dropout_p=0.3, rng=rng, rng_stream=9)
+    dQf, dKf, dVf = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attn_bwd(g, q, k, v, Of, _, dQf, dKf, dVf, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    close(dQ, dQf.cpu(), tol=5e-4, name="dQ"); close(dK, dKf.cpu(), tol=5e-4, name="dK"); close(dV, dVf.cpu(), tol=5e-4, name="dV")
+
+
 def test_attention_dropout_fwd_bwd_consistent():
     """With dropout the kernel's gradients must be the gradients of its own (masked) forward:
     finite-difference check of sum(O * G) with respect to V (linear in V -> exact up to rounding)."""

@@ -20,7 +20,12 @@ def main():
         O, lse = fwd()
         def bwd():
             ops.attn_bwd(go, q, k, v, O, lse, dq, dk, dv, N, 8, Lq, Lk, 32 ** -0.5, mask_mode=mode, kpm=kpm)
-        for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        cases = [("fwd", fwd), ("bwd", bwd)]
+        if ops.attn_mm_ok(N, 8, Lq, Lk):
+            O2, P, Pu = ops.attn_mm_fwd(q, k, v, N, 8, Lq, Lk, 32 ** -0.5, mask_mode=mode, kpm=kpm)
+            cases += [("mm fwd", lambda: ops.attn_mm_fwd(q, k, v, N, 8, Lq, Lk, 32 ** -0.5, mask_mode=mode, kpm=kpm)),
+                      ("mm bwd", lambda: ops.attn_mm_bwd(go, q, k, v, P, Pu, dq, dk, dv, N, 8, Lq, Lk, 32 ** -0.5))]
+        for name, fn in cases:
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
