@@ -207,7 +207,8 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         e0.record()
         lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
         e1.record()
-        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K, (M, N, K, a_mode, b_mode, int(split_k))))
+        nb = batch[0] if batch is not None else 1
+        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K * nb, (M, N, K, a_mode, b_mode, int(split_k), nb)))
         return
     lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
 
