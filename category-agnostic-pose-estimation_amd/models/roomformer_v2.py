@@ -205,6 +205,12 @@ class RoomFormerV2(nn.Module):
                 if len(self._decode_states) >= 4:
                     self._decode_states.pop(next(iter(self._decode_states)))
                 self._decode_states[key] = st
+        # the captured steps hold raw weight pointers: if the parameters were re-homed since (model.to(), arena creation,
+        # load into new storage) the graphs are dropped and re-captured
+        sentinel = tuple(p_.data_ptr() for p_ in list(dec.parameters())[:4]) + (self.query_embed.weight.data_ptr(),)
+        if st.get("weights_at") != sentinel:
+            st["graphs"], st["pool"], st["weights_at"] = {}, None, sentinel
+            st["calls"] = 0
         st["calls"] += 1
         caches = st["caches"]
         for layer, c in zip(dec.layers, caches):
