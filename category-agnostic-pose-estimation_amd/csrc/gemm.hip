@@ -702,6 +702,9 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
                  "cape_gemm_f32: batched launches take dense modes, no epilogue vectors, split_k 1, batch <= 65535");
   if (d->mask_src) CAPE_REQUIRE(d->split_k == 1, "cape_gemm_f32: mask_src needs split_k == 1");
   if (d->B_hi || d->B_lo) CAPE_REQUIRE(d->B_hi && d->B_lo && d->ldp >= d->K, "cape_gemm_f32: B planes need both pointers and ldp >= K");
+  CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
+  // register-stationary weights (gemm_rs.hip): dense A against a <= 256-deep weight, the token products of the transformer
+  if (d->precision == 1 && d->batch <= 1 && cape_gemm_rs_eligible(p, d->a_mode, d->b_mode)) return cape_gemm_rs_launch(p, d->b_mode, as_stream(stream));
   // weight-stationary kernel when the B operand comes with pre-split planes (see gemm_ws.hip); same epilogue semantics
   if (d->precision == 1 && d->batch <= 1 && cape_gemm_ws_eligible(p, d->a_mode)) return cape_gemm_ws_launch(p, d->a_mode, as_stream(stream));
 

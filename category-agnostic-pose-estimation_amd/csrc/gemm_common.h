@@ -57,6 +57,10 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 constexpr int BK = 32;
 
+// gemm_rs.hip: register-stationary weights (dense A, K in {64, 128, 256}, bf16x3), persistent over 64-row units
+bool cape_gemm_rs_eligible(const GemmP& p, int a_mode, int b_mode);
+int cape_gemm_rs_launch(const GemmP& p, int b_mode, hipStream_t stream);
+
 // gemm_ws.hip: weight-stationary bf16x3 kernel (A straight to registers, pre-split B planes through LDS)
 bool cape_gemm_ws_eligible(const GemmP& p, int a_mode);
 int cape_gemm_ws_launch(GemmP& p, int a_mode, hipStream_t stream);

@@ -59,6 +59,50 @@ def test_gemm_nt_epilogues(M, N, K):
         close(out3, x @ w.t(), name="split_k")
 
 
+@pytest.mark.parametrize("M,N,K,bm", [(43520, 256, 256, 0), (6400, 256, 256, 1), (6401, 384, 256, 0), (130, 1024, 256, 1),
+                                      (65, 32, 64, 0), (8191, 512, 128, 0), (1000, 100, 128, 1), (544, 256, 256, 0),
+                                      (4097, 768, 256, 0), (129, 36, 64, 1)])
+def test_gemm_rs_register_stationary(M, N, K, bm):
+    """Dense A against a <= 256-deep weight takes the register-stationary kernel (gemm_rs.hip) in bf16x3 mode: every
+    epilogue, strided operands, ragged M / N, both weight layouts; compared with an fp64 product."""
+    if ops.get_gemm_precision() != "bf16x3":
+        pytest.skip("the register-stationary kernel is the bf16x3 path")
+    x = rnd(M, K + 8, seed=1)[:, :K]                                   # lda = K + 8
+    w = rnd(N, K, seed=2, scale=K ** -0.5) if bm == 0 else rnd(K, N, seed=2, scale=K ** -0.5)
+    b, sc, res = rnd(N, seed=3), rnd(N, seed=5).abs() + 0.5, rnd(M, N, seed=4)
+    ref = (x.double() @ (w.double().t() if bm == 0 else w.double()))
+    xd_full = rnd(M, K + 8, seed=1).to(DEV)
+    xd = xd_full[:, :K]
+    wd = w.to(DEV)
+    out = torch.full((M, N + 4), 3.0, device=DEV)                      # ldc = N + 4: the pad columns must stay untouched
+    ops.gemm(xd, wd, out, M, N, K, b_mode=bm, lda=K + 8, ldc=N + 4, bias=b.to(DEV))
+    close(out[:, :N], (ref + b).float(), tol=3e-5, name="rs bias")
+    assert float((out[:, N:] - 3.0).abs().sum()) == 0
+    o2 = torch.empty(M, N, device=DEV)
+    ops.gemm(xd, wd, o2, M, N, K, b_mode=bm, lda=K + 8, bias=b.to(DEV), scale=sc.to(DEV), residual=res.to(DEV), relu=True)
+    want = F.relu(ref * sc + b + res).float()
+    close(o2, want, tol=3e-5, name="rs scale+bias+res+relu")
+    o3 = o2.clone()
+    ops.gemm(xd, wd, o3, M, N, K, b_mode=bm, lda=K + 8, accumulate=True)
+    close(o3, want + ref.float(), tol=5e-5, name="rs accumulate")
+    gate = (rnd(M, N, seed=9) > 0).float()
+    o4 = torch.empty(M, N, device=DEV)
+    ops.gemm(xd, wd, o4, M, N, K, b_mode=bm, lda=K + 8, mask_src=gate.to(DEV), mask_scale=1.25)
+    close(o4, (ref * gate * 1.25).float(), tol=3e-5, name="rs gate")
+    # dropout epilogue: same counter indexing as the tiled kernel -> identical masks
+    rng = ops.RngState(77, DEV)
+    o5, o6 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.gemm(xd, wd, o5, M, N, K, b_mode=bm, lda=K + 8, relu=True, dropout_p=0.1, rng=rng, rng_stream=5)
+    if K == 256 and N % 4 == 0:                                        # the tiled kernel via a split K that it alone serves
+        xa = torch.cat([xd, torch.zeros(M, 32, device=DEV)], 1).contiguous()
+        wa = torch.cat([wd, torch.zeros(N, 32, device=DEV)], 1).contiguous() if bm == 0 else torch.cat([wd, torch.zeros(32, N, device=DEV)], 0).contiguous()
+        ops.gemm(xa, wa, o6, M, N, K + 32, b_mode=bm, relu=True, dropout_p=0.1, rng=rng, rng_stream=5)
+        assert bool(((o5 == 0) == (o6 == 0)).all()), "dropout masks differ between the two kernels"
+        close(o5, o6, tol=3e-5, name="rs dropout values")
+    keep = (o5 != 0).float().mean().item()
+    assert 0.3 < keep < 0.6                                            # relu keeps ~half, dropout 90 % of those
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 256, 256), (32, 256, 256), (64, 1024, 256), (32, 256, 1024), (7, 3, 36), (33, 70, 516)])
 def test_gemm_skinny_rows(M, N, K):
     """M <= 64 dense NT products take the exact-fp32 FMA kernel (the cached decode step): epilogues and strided outputs."""

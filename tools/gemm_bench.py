@@ -16,7 +16,12 @@ SHAPES = [  # (M, N, K, a_mode, b_mode, split_k)
     # M = 256 x 128: one full round of 128x128 tiles at 2 blocks per CU (tile-efficiency comparison without quantisation)
     (32768, 256, 256, 0, 0, 1), (32768, 1024, 256, 0, 0, 1), (32768, 256, 1024, 0, 0, 1), (32768, 256, 256, 0, 1, 1),
     (1024, 256, 6400, 1, 1, 16), (256, 1024, 6400, 1, 1, 16), (6400, 256, 1024, 0, 0, 1), (6400, 256, 1024, 0, 1, 1),
+    (43520, 1024, 256, 0, 1, 1), (6400, 256, 256, 0, 1, 1), (6400, 768, 256, 0, 0, 1), (544, 256, 256, 0, 0, 1), (544, 512, 256, 0, 0, 1),
+    (131072, 256, 64, 0, 0, 1), (32768, 512, 128, 0, 0, 1), (43520, 256, 128, 0, 1, 1), (43520, 128, 256, 0, 0, 1),
+    (8192, 1024, 256, 0, 0, 1), (2176, 256, 256, 0, 0, 1),
 ]
+if os.environ.get("GEMM_BENCH_RS_ONLY"):
+    SHAPES = [s for s in SHAPES if s[3] == 0 and s[5] == 1 and s[2] in (64, 128, 256)]
 
 
 def main():
@@ -38,7 +43,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / it
         line = f"M={M:6d} N={N:5d} K={K:6d} am={am} bm={bm} sk={sk:2d}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s"
-        if am == 0 and sk == 1 and ops.get_gemm_precision() == "bf16x3":      # weight-stationary kernel on the same product
+        if am == 0 and sk == 1 and ops.get_gemm_precision() == "bf16x3" and os.environ.get("GEMM_BENCH_WS"):      # weight-stationary kernel on the same product
             if bm == 0:
                 hi, lo, _, _ = ops.split_planes(B, N, 1, K, want_transposed=False)
             else:
