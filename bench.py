@@ -6,10 +6,15 @@
 
 A step = one pass of the hot path over one batch of synthetic episodes: forward (backbone, encoder,
 support encoder, decoder), fused criterion, backward, gradient all-reduce (N > 1), global-norm clip,
-AdamW -- dropout ON (train mode), exact fp32 arithmetic.  Workload = BASELINE.json configs[1]:
+AdamW -- dropout ON (train mode); fp32 storage and accumulation, the GEMMs as a bf16x3 split on the bf16 matrix cores by
+default (CAPE_GEMM_PRECISION=f32 = exact fp32 MFMA; that leg is timed too and reported as `alt_exact_f32`).
+Workload = BASELINE.json configs[1]:
 1-shot, 256x256, 17 keypoints, ResNet-50 + deformable transformer, 16 episodes x 2 queries per GPU.
 Weak scaling: every rank processes its own 16 episodes (pure data parallel, episodes are independent).
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.  At N = 1 the line also carries
+`decode` (BASELINE configs[4]: 5-shot KV-cached autoregressive decode at 512x512 with 68 support keypoints -- time per decode
+step, tokens/s, eager and replayed hipGraphs, against the weight-streaming roof) and `pck_check` (the same synthetic
+episode decoded by the product and by the CPU oracle: PCK@0.2 of both, token streams compared).
 """
 import argparse
 import json
@@ -98,6 +103,61 @@ def cpu_baseline(args_ns, seconds_budget=20.0):
             "sample": f"{n} train steps of 2 episodes x 2 queries, 256x256, 17 kpt (oracle/cape_ref.py, torch CPU fp32, {cores} threads)"}
 
 
+def pck_check(device, steps=24):
+    """One synthetic episode (2 queries, 256x256, 17 keypoints) decoded for `steps` tokens by the product (HIP) and by the
+    oracle (oracle/cape_ref.py on the host, the checker): PCK@0.2 of both against the synthetic ground truth, token streams
+    and logits compared.  Random-init weights, identical in both (the product's state_dict feeds the oracle)."""
+    import argparse as _ap
+    from cape_amd.datasets import DiscreteTokenizerV2, episodic_collate_fn
+    from cape_amd.datasets.synthetic import SyntheticEpisodes
+    from cape_amd.models import build_model
+    from cape_amd.models.cape_model import build_cape_model
+    from cape_amd.models.engine_cape import extract_keypoints_from_predictions
+    from cape_amd.models.train_cape_episodic import get_args_parser
+    from cape_amd.util.eval_utils import PCKEvaluator
+    from oracle import cape_ref
+    args = _ap.ArgumentParser(parents=[get_args_parser()]).parse_args(["--use_geometric_encoder", "--use_gcn_preenc"])
+    torch.manual_seed(7)
+    tok = DiscreteTokenizerV2(44, steps)
+    base, _ = build_model(args, tokenizer=tok)
+    model = build_cape_model(args, base).to(device).eval()
+    with torch.no_grad():                       # spread the class head so that the stream is not all-<coord>
+        model.base_model.class_embed[5].bias.copy_(torch.tensor([0.3, 0.0, -0.2]))
+    ds = SyntheticEpisodes(tok, 1, 256, 17, 2, seed=11)
+    b = episodic_collate_fn([ds[0]])
+    os.environ["WARN_INCOMPLETE_GENERATION"] = "0"
+    with torch.no_grad():
+        p = model.forward_inference(b["query_images"].to(device), b["support_coords"].to(device), b["support_masks"].to(device),
+                                    skeleton_edges=b["support_skeletons"], graph=False)
+    sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        o = cape_ref.cape_forward_inference(sd, cape_ref.Cfg(), b["query_images"], b["support_coords"], b["support_masks"],
+                                            b["support_skeletons"], max_len=steps)
+
+    def pck_of(logits, coords):
+        ev = PCKEvaluator(threshold=0.2)
+        k = extract_keypoints_from_predictions(coords, logits)
+        pl, gl, bw, bh, vl = [], [], [], [], []
+        for i, m in enumerate(b["query_metadata"]):
+            n = len(m["visibility"])
+            pk = k[i, :n] if k.shape[1] >= n else torch.cat([k[i], torch.zeros(n - k.shape[1], 2)])
+            pl.append(pk.numpy() * 512.0); gl.append(np.asarray(m["keypoints"]) * 512.0)
+            bw.append(m["bbox_width"]); bh.append(m["bbox_height"]); vl.append(m["visibility"])
+        ev.add_batch(pl, gl, bw, bh, category_ids=[1] * len(pl), visibility=vl)
+        return ev.get_results()["pck_overall"]
+
+    T = min(p["logits"].shape[1], o["logits"].shape[1])
+    lp, lo = p["logits"].cpu()[:, :T], o["logits"][:, :T]
+    pck_p, pck_o = pck_of(p["logits"].cpu(), p["coordinates"].cpu()), pck_of(o["logits"], o["coordinates"])
+    return {"workload": f"1 episode x 2 queries, 256x256, 17 kpt, {steps} decode steps, random-init weights",
+            "pck_product": round(pck_p, 6), "pck_oracle": round(pck_o, 6), "pck_equal": bool(abs(pck_p - pck_o) <= 1e-3),
+            "steps_product": int(p["logits"].shape[1]), "steps_oracle": int(o["logits"].shape[1]),
+            "tokens_equal": bool(p["logits"].shape == o["logits"].shape and torch.equal(lp.argmax(-1), lo.argmax(-1))),
+            "max_abs_logit_diff": round(float((lp - lo).abs().max()), 6),
+            "max_abs_coord_diff": round(float((p["coordinates"].cpu()[:, :T] - o["coordinates"][:, :T]).abs().max()), 7)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,8 +168,9 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as one captured hipGraph (runtime/graph_step.py) instead of launching every kernel "
-                         "from Python; measured round 1: host cost 30 -> 6 ms per step, wall 38.6 -> 39.7 ms (GPU-bound)")
+                    help="time only the hipGraph replay of the captured step (runtime/graph_step.py); by default at N = 1 both "
+                         "launch modes are timed over the same K steps and the faster one is the headline (both are reported)")
+    ap.add_argument("--no_decode", action="store_true", help="skip the configs[4] decode block and the PCK check")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -156,15 +217,13 @@ def main():
     scale = 1.0 / world
     last = {}
 
-    # world == 1: the step is captured into one hipGraph after two eager calls and replayed (runtime/graph_step.py);
+    # world == 1: the step can be captured into one hipGraph after two eager calls and replayed (runtime/graph_step.py);
     # data-parallel runs keep the eager step (bucket all-reduces are launched from Python hooks)
-    gstep = None
-    if world == 1 and a.graph:
-        from cape_amd.runtime.graph_step import GraphedTrainStep
-        gstep = GraphedTrainStep(model, crit, opt, loss_scale=scale, edge_capacity=2048, eager_steps=2)
+    state = {"gstep": None}
 
     def step(i, eager=False):
         b = batches[i % len(batches)]
+        gstep = state["gstep"]
         if gstep is not None and not eager:
             last["loss"] = gstep(b["images"], b["support_coords"], b["support_mask"], b["targets"], b["skeleton"])["_total"]
             return
@@ -184,35 +243,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region(label, warmup):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides."""
+        for i in range(warmup):
+            step(i)
+            if i == 0:
+                torch.cuda.synchronize()
+                log(f"[{label}] first step done")
+        sync()
+        log(f"[{label}] timing {a.steps} steps")
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(warmup + i)
+        t_enq = time.perf_counter() - t0             # host time to enqueue the steps (launch-bound if ~ the timed region)
+        sync()
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        step(warmup + a.steps)                       # one step into an empty queue: pure host launch cost, no back-pressure
+        t_one = time.perf_counter() - t1
+        sync()
+        log(f"[{label}] host enqueue {t_enq / a.steps * 1e3:.2f} ms/step in the timed region; {t_one * 1e3:.2f} ms for one step "
+            f"into an empty queue; timed region {dt:.3f} s")
+        return {"dt": dt, "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 2), "host_ms_one_step": round(t_one * 1e3, 2)}
+
     log(f"model built, {len(batches)} batches of {B} episodes resident; warm-up x{a.warmup}")
-    for i in range(a.warmup):
-        step(i)
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first step done")
-    sync()
-    log(f"timing {a.steps} steps")
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    t_enq = time.perf_counter() - t0                 # host time to enqueue the steps (launch-bound if ~ the timed region)
-    sync()
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    step(a.warmup + a.steps)                         # one step into an empty queue: pure host launch cost, no back-pressure
-    t_one = time.perf_counter() - t1
-    sync()
-    log(f"host enqueue {t_enq / a.steps * 1e3:.2f} ms/step in the timed region; {t_one * 1e3:.2f} ms for one step into an empty queue")
+    modes = {}
+    if not (world == 1 and a.graph):
+        modes["eager"] = timed_region("eager", a.warmup)
+    if world == 1:
+        from cape_amd.runtime.graph_step import GraphedTrainStep
+        state["gstep"] = GraphedTrainStep(model, crit, opt, loss_scale=scale, edge_capacity=2048, eager_steps=2)
+        modes["graph"] = timed_region("graph", max(a.warmup, 4))      # 2 eager calls + capture + first replay are warm-up
+    best = min(modes, key=lambda k: modes[k]["dt"])
+    if best != "graph":
+        state["gstep"] = None
+    dt = modes[best]["dt"]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    log(f"timed region {dt:.3f} s")
+    log(f"headline launch mode: {best}; timed region {dt:.3f} s")
     loss = float(last["loss"])
     assert np.isfinite(loss), "non-finite loss in the bench"
     episodes = B * world * a.steps
     value = episodes / dt
     ms_per_step = dt / a.steps * 1e3
+    launch_modes = {k: {"value": round(B * world * a.steps / v["dt"], 3), "ms_per_step": round(v["dt"] / a.steps * 1e3, 3),
+                        "host_enqueue_ms_per_step": v["host_enqueue_ms_per_step"], "host_ms_one_step": v["host_ms_one_step"]}
+                    for k, v in modes.items()}
+    comm = None
+    if ddp is not None:
+        comm = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                "allreduce_bytes_per_step": ddp.stats["bytes_per_step"], "buckets": len(ddp.buckets),
+                "exposed_comm_ms_last_step": round(ddp.exposed_comm_ms(), 3)}
 
     roofline = None
     if not a.no_roofline and rank == 0:
@@ -240,7 +323,9 @@ def main():
         # read from inside the process, so the figure is the committed one, not re-measured by this run
         traffic, alg_bytes = None, None
         try:
-            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")))
+            import glob
+            tfile = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_gemm_traffic.json")))[-1]
+            tr = json.load(open(tfile))
             traffic = round(tr["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
@@ -256,13 +341,15 @@ def main():
         bound = "hbm" if t_hbm >= t_mfma else "mfma"
         main, other = (hbm_view, mfma_view) if bound == "hbm" else (mfma_view, hbm_view)
         roofline = {"bound": bound, **main, "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (profiles/r01_gemm_traffic.json)",
+                    "traffic_unit": "HBM bytes per launch, from the committed rocprofv3 --pmc passes of this command (newest "
+                                    "profiles/r*_gemm_traffic.json; counters cannot be read in-process)",
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
                     "roof_times_us": {"mfma": round(t_mfma * 1e6, 2), "hbm": round(t_hbm * 1e6, 2)},
                     "other_roof": {"bound": "mfma" if bound == "hbm" else "hbm", **other},
                     "peak_note": (("bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product (bf16x3 split)"
                                    if split else "fp32 MFMA dense peak") + "; HBM3E 8 TB/s"),
-                    "kernel": "gemm_kernel<BM,BN,AMODE,BMODE,VEC,PREC,KFULL> (implicit-GEMM family, all instantiations; "
+                    "kernel": "GEMM family: gemm_rs_kernel<NW,BMODE,KS,EPI> (register-stationary weights, K <= 256) + "
+                              "gemm_kernel<BM,BN,AMODE,BMODE,VEC,PREC,KFULL> (tiled implicit GEMM), all instantiations; "
                               + ("bf16x3 split on bf16 MFMA" if split else "exact fp32 MFMA") + ")",
                     "launches_per_step": r["launches"] // nprof,
                     "avg_launch_us": round(avg_s * 1e6, 2),
@@ -277,6 +364,7 @@ def main():
     # the same step with every GEMM on exact fp32 MFMA (CAPE_GEMM_PRECISION=f32), for reference
     alt = None
     if world == 1 and not a.no_roofline and ops.get_gemm_precision() != "f32":
+        state["gstep"] = None
         ops.set_gemm_precision("f32")
         for i in range(2):
             step(i, eager=True)
@@ -287,12 +375,39 @@ def main():
             step(i, eager=True)
         sync()
         dta = time.perf_counter() - t1
+        side = HF.Runtime.use_side_stream
+        HF.Runtime.use_side_stream = False
+        ops.GemmProfiler.start()
+        step(0, eager=True)
+        rf = ops.GemmProfiler.stop()
+        HF.Runtime.use_side_stream = side
         ops.set_gemm_precision("bf16x3")
-        alt = {"gemm_precision": "f32 (exact fp32 MFMA)", "launch": "eager", "value": round(B * nalt / dta, 3), "ms_per_step": round(dta / nalt * 1e3, 3)}
+        ach32 = rf["flops"] / (rf["ms"] * 1e-3) / 1e12
+        alt = {"gemm_precision": "f32 (exact fp32 MFMA)", "launch": "eager", "value": round(B * nalt / dta, 3), "ms_per_step": round(dta / nalt * 1e3, 3),
+               "roofline": {"bound": "mfma", "achieved": round(ach32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach32 / PEAK_F32_MFMA_TFLOPS, 4), "gemm_ms_per_step": round(rf["ms"], 2),
+                            "kernel": "gemm_kernel<..., PREC 0> (v_mfma_f32_32x32x2_f32)"}}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(args)
+
+    decode, pck = None, None
+    if rank == 0 and world == 1 and not a.no_decode:
+        # free the training state first: the decode model is a second instance (512x512, patch-2 input_proj)
+        from cape_amd.runtime.decode_bench import decode_benchmark
+        torch.cuda.synchronize()
+        try:
+            d1 = decode_benchmark(device, episodes=1)                     # configs[4] as stated: one 5-shot episode in flight
+            d16 = decode_benchmark(device, episodes=16)                   # the same step with 32 images in flight
+            decode = dict(d1, batched_32_images={k: d16[k] for k in ("images", "steps", "us_per_step_eager", "us_per_step_graph",
+                                                                   "tokens_per_s", "images_per_s_200_steps", "roofline")})
+            log(f"decode: {d1['us_per_step_graph']} us/step (1 episode, graphs), {d16['us_per_step_graph']} us/step at 32 images")
+            pck = pck_check(device)
+            log(f"pck_check: {pck}")
+        except Exception as e:                                            # the training line must not be lost to the extra block
+            log(f"decode block failed: {type(e).__name__}: {e}")
+            decode = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         gflop_ep = GFLOP_PER_EPISODE_256 * (a.image_size / 256.0) ** 2
@@ -309,10 +424,14 @@ def main():
                        "weights": "random init (no checkpoint offline)"},
             "loss": round(loss, 4),
             "model_tflops": round(value * gflop_ep / 1e3, 2),
-            "model_frac_of_f32_mfma_peak": round(value * gflop_ep / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "model_frac_of_mfma_peak": round(value * gflop_ep / 1e3 / ((PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.get_gemm_precision() == "bf16x3"
+                                                                          else PEAK_F32_MFMA_TFLOPS) * world), 4),
+            "model_frac_note": "whole-step algorithmic TFLOP/s over the peak of the arithmetic issued (bf16 dense 2500 / 3 MFMAs per "
+                               "product for the bf16x3 split; 157.3 for exact fp32)",
             "gemm_precision": ops.get_gemm_precision(),
             "roofline": roofline, "cpu_baseline": cpu, "alt_exact_f32": alt,
-            "launch": "hipGraph replay of the captured step" if gstep is not None else "eager (one launch per kernel from Python)",
+            "launch": "hipGraph replay of the captured step" if best == "graph" else "eager (one launch per kernel from Python)",
+            "launch_modes": launch_modes, "comm": comm, "decode": decode, "pck_check": pck,
         }
         print(json.dumps(line))
     if world > 1:

@@ -23,6 +23,27 @@ __global__ void add_kernel(const float* a, const float* b, float* o, long long n
   GSTRIDE(i, n & 3) o[(n4 << 2) + i] = a[(n4 << 2) + i] + b[(n4 << 2) + i];
 }
 
+// o = sum of up to 8 equally shaped tensors (gradient fan-in of a tensor with several consumers): one pass, k reads + 1 write
+struct AddNP { const float* src[8]; int k; };
+__global__ void add_n_kernel(const AddNP p, float* o, long long n) {
+  const long long n4 = n >> 2;
+  GSTRIDE(i, n4) {
+    float4 s = reinterpret_cast<const float4*>(p.src[0])[i];
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+      if (j < p.k) {
+        const float4 y = reinterpret_cast<const float4*>(p.src[j])[i];
+        s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+      }
+    reinterpret_cast<float4*>(o)[i] = s;
+  }
+  GSTRIDE(i, n & 3) {
+    float s = p.src[0][(n4 << 2) + i];
+    for (int j = 1; j < p.k; ++j) s += p.src[j][(n4 << 2) + i];
+    o[(n4 << 2) + i] = s;
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* x, float* o, int N, int C, int H, int W, int Cp) {
   const long long tot = (long long)N * H * W * Cp;
   GSTRIDE(i, tot) {
@@ -284,6 +305,23 @@ extern "C" int cape_add_f32(const float* a, const float* b, float* out, long lon
                "cape_add_f32: pointers must be 16-byte aligned");
   LAUNCH1(add_kernel, n / 4 + 1, 1, a, b, out, n);
   CAPE_LAUNCH_CHECK("cape_add_f32");
+  return 0;
+}
+
+extern "C" int cape_add_n_f32(const float* const* srcs, int k, float* out, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(srcs && out && k >= 1 && k <= 8 && n >= 0, "cape_add_n_f32: 1..8 sources");
+  if (n == 0) return 0;
+  AddNP p;
+  uintptr_t al = reinterpret_cast<uintptr_t>(out);
+  for (int j = 0; j < 8; ++j) {
+    p.src[j] = j < k ? srcs[j] : srcs[0];
+    CAPE_REQUIRE(p.src[j] != nullptr, "cape_add_n_f32: null source");
+    al |= reinterpret_cast<uintptr_t>(p.src[j]);
+  }
+  CAPE_REQUIRE((al & 15) == 0, "cape_add_n_f32: pointers must be 16-byte aligned");
+  p.k = k;
+  LAUNCH1(add_n_kernel, n / 4 + 1, 1, p, out, n);
+  CAPE_LAUNCH_CHECK("cape_add_n_f32");
   return 0;
 }
 

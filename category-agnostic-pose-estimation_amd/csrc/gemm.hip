@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP pin) {
         if (!interior && row >= p.M) continue;
         float v = acc[i][j][r];
         float* cp = p.C + (long long)row * p.ldc + col;
-        if (atomic) { atomicAdd(cp, v); continue; }
+        if (atomic) { atomicAdd(cp, split == 0 ? v + bi : v); continue; }     // the bias rides with the first k-split
         v = v * sc + bi;
         if (p.residual) v += p.residual[(long long)row * p.ldr + col];
         if (p.relu) v = fmaxf(v, 0.f);
@@ -665,8 +665,8 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   CAPE_REQUIRE(d->A && d->B && d->C, "cape_gemm_f32: null operand");
   CAPE_REQUIRE(d->split_k >= 1, "cape_gemm_f32: split_k must be >= 1");
   if (d->split_k > 1)
-    CAPE_REQUIRE(!d->scale && !d->bias && !d->residual && !d->relu && d->dropout_p == 0.f,
-                 "cape_gemm_f32: split_k > 1 allows no epilogue op besides accumulation");
+    CAPE_REQUIRE(!d->scale && !d->residual && !d->relu && d->dropout_p == 0.f,
+                 "cape_gemm_f32: split_k > 1 allows no epilogue op besides the bias and accumulation");
   if (d->a_mode == 2 || d->a_mode == 3 || d->b_mode == 2 || d->b_mode == 3) {
     CAPE_REQUIRE(d->cC % 4 == 0 && d->cO % 4 == 0, "cape_gemm_f32: conv channels must be multiples of 4 (C=%d, O=%d)", d->cC, d->cO);
     CAPE_REQUIRE(d->cStride >= 1 && d->cKH >= 1 && d->cKW >= 1, "cape_gemm_f32: bad conv geometry");

@@ -223,14 +223,16 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
         const float* x0 = EPI == 1 ? p.residual + (long long)rb * ldr : EPI == 2 ? p.mask_src + (long long)rb * ldm : c0;
         const int ldx = EPI == 1 ? ldr : EPI == 2 ? ldm : ldc;
         const unsigned lo_x = EPI == 1 ? lo_r : EPI == 2 ? lo_m : lo_c;
-        const int rmax = full ? 63 : max(rlim - 1, 0);          // clamp row offset for the loads of a ragged last unit
+        // a ragged last unit clamps the absolute row (rows >= M are loaded from row M - 1 and never stored)
+        const float* xb = EPI == 1 ? p.residual : EPI == 2 ? p.mask_src : p.C;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           float xv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int i = 8 * g + e, roff = (i & 3) + 8 * (i >> 2);
-            xv[e] = full ? x0[lo_x + (unsigned)(roff * ldx)] : x0[lo_x + (unsigned)(min(roff, rmax) * ldx)];
+            if (full) xv[e] = x0[lo_x + (unsigned)(roff * ldx)];
+            else xv[e] = xb[(long long)min(rb + roff + 4 * h, p.M - 1) * ldx + col];
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {

@@ -23,20 +23,31 @@ __global__ void support_embed_fwd_kernel(const float* coords, const float* W0, c
   }
 }
 
-__global__ void support_embed_bwd_kernel(const float* d_h, const float* h, const float* coords, float* dW0, float* db0,
-                                         long long R, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dW0 (C, 2) += sum_r g[r][c] * coords[r], db0 += sum_r g[r][c], g = d_h gated by relu.  Rows are split over blockIdx.y
+// (32 rows per block) and over the 4 waves of a block (lane = channel: coalesced 256-byte row reads); partial sums meet in
+// LDS and leave as three float atomics per channel and block (R / 32 adders per address).
+constexpr int SEB_ROWS = 32;
+__global__ void __launch_bounds__(256) support_embed_bwd_kernel(const float* d_h, const float* h, const float* coords, float* dW0,
+                                                                float* db0, long long R, int C) {
+  __shared__ float part[4][3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long long r0 = (long long)blockIdx.y * SEB_ROWS, r1 = min(R, r0 + SEB_ROWS);
   float gx = 0.f, gy = 0.f, gb = 0.f;
-  for (long long r = 0; r < R; ++r) {
-    const float g = h[r * C + c] > 0.f ? d_h[r * C + c] : 0.f;
-    gx += g * coords[r * 2 + 0];
-    gy += g * coords[r * 2 + 1];
-    gb += g;
+  if (c < C)
+    for (long long r = r0 + w; r < r1; r += 4) {
+      const float g = h[r * C + c] > 0.f ? d_h[r * C + c] : 0.f;
+      gx += g * coords[r * 2 + 0];
+      gy += g * coords[r * 2 + 1];
+      gb += g;
+    }
+  part[w][0][lane] = gx; part[w][1][lane] = gy; part[w][2][lane] = gb;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    atomicAdd(&dW0[c * 2 + 0], part[0][0][lane] + part[1][0][lane] + part[2][0][lane] + part[3][0][lane]);
+    atomicAdd(&dW0[c * 2 + 1], part[0][1][lane] + part[1][1][lane] + part[2][1][lane] + part[3][1][lane]);
+    atomicAdd(&db0[c], part[0][2][lane] + part[1][2][lane] + part[2][2][lane] + part[3][2][lane]);
   }
-  dW0[c * 2 + 0] += gx;
-  dW0[c * 2 + 1] += gy;
-  db0[c] += gb;
 }
 
 __global__ void adjacency_kernel(const int* edges, const int* edge_start, const uint8_t* mask, float* adj, int P) {
@@ -126,8 +137,10 @@ extern "C" int cape_support_embed_bwd(const float* d_h, const float* h, const fl
                                       int P, int C, cape_stream_t stream) {
   CAPE_REQUIRE(d_h && h && coords && dW0 && db0, "cape_support_embed_bwd: null pointer");
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(support_embed_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), d_h, h, coords, dW0, db0,
-                     (long long)N * P, C);
+  const long long R = (long long)N * P;
+  CAPE_REQUIRE((R + SEB_ROWS - 1) / SEB_ROWS <= 65535, "cape_support_embed_bwd: too many rows");
+  hipLaunchKernelGGL(support_embed_bwd_kernel, dim3((C + 63) / 64, (unsigned)((R + SEB_ROWS - 1) / SEB_ROWS)), dim3(256), 0,
+                     as_stream(stream), d_h, h, coords, dW0, db0, R, C);
   CAPE_LAUNCH_CHECK("cape_support_embed_bwd");
   return 0;
 }

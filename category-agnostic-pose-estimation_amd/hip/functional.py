@@ -317,10 +317,19 @@ class ConvFn(torch.autograd.Function):
         res = _c(residual) if residual is not None else None
         geom = (N, H, W, C, KH, KW, stride, pad, OH, OW, O)
         dense = KH == 1 and KW == 1 and stride == 1 and pad == 0
+        # few output tiles over a deep contraction (the 3x3/s2 input_proj conv on C5: 512 x 256 x 18432 = 32 tiles): split K,
+        # the bias rides with the first split (no BN / ReLU / residual on these convolutions)
+        # (training only: the atomic k-split sums in arrival order, and inference keeps run-to-run bitwise reproducibility --
+        # the replayed decode graphs are tested bit-for-bit against the eager loop)
+        sk = ops.pick_split_k(M, O, K) if (scale is None and res is None and not relu and torch.is_grad_enabled()) else 1
+        sk = sk if sk >= 8 else 1
+        if sk > 1:
+            y.zero_()
+        kw = dict(bias=shift, split_k=sk, accumulate=True) if sk > 1 else dict(scale=scale, bias=shift, residual=res, relu=relu)
         if dense:
-            ops.gemm(x, wp, y, M, O, K, scale=scale, bias=shift, residual=res, relu=relu)
+            ops.gemm(x, wp, y, M, O, K, **kw)
         else:
-            ops.gemm(x, wp, y, M, O, K, a_mode=2, b_mode=0, conv=geom, scale=scale, bias=shift, residual=res, relu=relu)
+            ops.gemm(x, wp, y, M, O, K, a_mode=2, b_mode=0, conv=geom, **kw)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
         ctx.w_ref, ctx.shift_ref = weight, shift
         ctx.meta = (geom, dense, relu, shift is not None, residual is not None)
@@ -455,6 +464,34 @@ class AddFn(torch.autograd.Function):
 
 def add(a, b):
     return AddFn.apply(a, b)
+
+
+class FanOutFn(torch.autograd.Function):
+    """x -> k aliases of x for k consumers.  Autograd would sum the k incoming gradients of a multiply-used tensor with k-1
+    `at::add` launches; here they arrive as separate arguments and are summed by ONE pass of cape_add_n_f32 (k reads, one
+    write).  Gradients that autograd reports as None (an unused alias) are skipped."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [_c(g) for g in grads if g is not None]
+        if not gs:
+            return None, None
+        out = gs[0]
+        for i in range(0, len(gs) - 1, 7):                  # 8 sources per launch
+            out = ops.add_n([out] + gs[1 + i:8 + i]) if len(gs) > 1 else out
+        return out, None
+
+
+def fanout(x, k):
+    """k aliases of x whose gradients are summed by one HIP launch (no-op outside autograd or for k == 1)."""
+    if k == 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * k
+    return FanOutFn.apply(x, k)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -651,16 +688,25 @@ class MHAFn(torch.autograd.Function):
             d_in_w = d_in_b = d_out_w = d_out_b = None
         else:
             in_grads()
+        # input gradients; when the same tensor came in as k and v (support features) or as q, k and v (self-attention of the
+        # support encoder) the products accumulate into ONE buffer (GEMM epilogue C += ...) and the duplicates report None
         dq_in = dk_in = dv_in = None
-        if ctx.needs_input_grad[0]:
-            dq_in = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
-            ops.gemm(dq.view(-1, C), in_w, dq_in, Mq, C, C, a_mode=0, b_mode=1)
-        if ctx.needs_input_grad[1]:
+        need_q, need_k, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if need_k:
             dk_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
             ops.gemm(dk.view(-1, C), in_w[C:], dk_in, Mk, C, C, a_mode=0, b_mode=1)
-        if ctx.needs_input_grad[2]:
-            dv_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
-            ops.gemm(dv.view(-1, C), in_w[2 * C:], dv_in, Mk, C, C, a_mode=0, b_mode=1)
+        if need_v:
+            if kv_same and dk_in is not None:
+                ops.gemm(dv.view(-1, C), in_w[2 * C:], dk_in, Mk, C, C, a_mode=0, b_mode=1, accumulate=True)
+            else:
+                dv_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+                ops.gemm(dv.view(-1, C), in_w[2 * C:], dv_in, Mk, C, C, a_mode=0, b_mode=1)
+        if need_q:
+            if qk_same and dk_in is not None:
+                ops.gemm(dq.view(-1, C), in_w, dk_in, Mq, C, C, a_mode=0, b_mode=1, accumulate=True)
+            else:
+                dq_in = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+                ops.gemm(dq.view(-1, C), in_w, dq_in, Mq, C, C, a_mode=0, b_mode=1)
         return dq_in, dk_in, dv_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None, None
 
 

@@ -47,6 +47,33 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class DecodeLinearDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_int), ("K", c_int), ("Nout", c_int),
+        ("X", c_void_p), ("ldx", c_longlong), ("in_gamma", c_void_p), ("in_beta", c_void_p), ("in_add", c_void_p), ("ld_add", c_longlong),
+        ("W", c_void_p), ("ldw", c_longlong), ("bias", c_void_p),
+        ("X2", c_void_p), ("ldx2", c_longlong), ("K2", c_int), ("W2", c_void_p), ("ldw2", c_longlong), ("n2", c_int),
+        ("R", c_void_p), ("ldr", c_longlong), ("res_gamma", c_void_p), ("res_beta", c_void_p),
+        ("relu", c_int), ("nseg", c_int), ("seg", c_int), ("out", c_void_p * 3), ("ldo", c_longlong * 3),
+    ]
+
+
+class DecodeTailDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_int), ("L", c_int),
+        ("P4", c_void_p), ("ldp", c_longlong), ("g3", c_void_p), ("b3", c_void_p),
+        ("W1", c_void_p), ("B1", c_void_p), ("W2", c_void_p), ("B2", c_void_p), ("W3", c_void_p), ("B3", c_void_p),
+        ("ref", c_void_p),
+        ("Wc", c_void_p), ("Bc", c_void_p), ("ncls", c_int),
+        ("Wp", c_void_p), ("Bp", c_void_p), ("gp", c_void_p), ("bp", c_void_p),
+        ("dim_t", c_void_p), ("vr", c_void_p),
+        ("ref_out", c_void_p), ("ld_ref", c_longlong),
+        ("qpos_out", c_void_p), ("refin_out", c_void_p),
+        ("cls_out", c_void_p), ("ld_cls", c_longlong),
+        ("hs_out", c_void_p), ("ld_hs", c_longlong),
+    ]
+
+
 P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
 _SIGS = {
     "cape_rng_advance": [P, P],
@@ -65,6 +92,7 @@ _SIGS = {
     "cape_attn_softmax_fwd": [P, P, P, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_softmax_bwd": [P, P, I, I, I, I, F, F, P, U32, P],
     "cape_add_f32": [P, P, P, LL, P],
+    "cape_add_n_f32": [POINTER(c_void_p), I, P, LL, P],
     "cape_gelu_f32": [P, P, LL, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],
     "cape_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
@@ -94,6 +122,9 @@ _SIGS = {
     "cape_adamw_step": [P, P, P, P, LL, F, F, F, F, F, F, P, P, P],
     "cape_step_increment": [P, P],
     "cape_decode_next_tokens": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "cape_decode_advance": [P, LL, P, LL, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P, P],
+    "cape_decode_linear": [POINTER(DecodeLinearDesc), P],
+    "cape_decode_tail": [POINTER(DecodeTailDesc), P],
 }
 EXPORTS = ["cape_last_error", "cape_abi_version", "cape_groupnorm_workspace_bytes"] + list(_SIGS)
 _lib.cape_groupnorm_workspace_bytes.argtypes = [I, I, I]

@@ -415,6 +415,21 @@ def add(a, b):
     return out
 
 
+def add_n(tensors):
+    """Sum of 1..8 equally shaped contiguous tensors in one pass."""
+    k = len(tensors)
+    assert 1 <= k <= 8
+    for t in tensors:
+        _chk(t, "add_n.src")
+        assert t.shape == tensors[0].shape
+    if k == 1:
+        return tensors[0]
+    out = torch.empty_like(tensors[0])
+    arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
+    lib.call("cape_add_n_f32", arr, k, _p(out), out.numel(), _stream())
+    return out
+
+
 def gelu(x):
     _chk(x, "gelu.x")
     out = torch.empty_like(x)
@@ -509,6 +524,16 @@ def token_embed_fwd(table, seqs, deltas):
     out = torch.empty(R, C, dtype=_F32, device=table.device)
     lib.call("cape_token_embed_fwd", _p(table), *[_p(s) for s in seqs], *[_p(d) for d in deltas], _p(out), R, C, V, _stream())
     return out
+
+
+def token_embed_fwd_into(table, tok_4n, delta_4n, out):
+    """tok (4, N) int64 rows [11, 12, 21, 22], delta (4, N) rows [x1, x2, y1, y2] (the decode loop's state layout) -> out (N, C)."""
+    _chk(table, "tok.table"); _chk(out, "tok.out"); _chk(tok_4n, "tok.tok", dtype=torch.int64); _chk(delta_4n, "tok.delta")
+    R = tok_4n.shape[1]
+    V, C = table.shape
+    assert tok_4n.shape == (4, R) and delta_4n.shape == (4, R) and out.numel() == R * C
+    lib.call("cape_token_embed_fwd", _p(table), _p(tok_4n[0]), _p(tok_4n[2]), _p(tok_4n[1]), _p(tok_4n[3]), _p(delta_4n[0]),
+             _p(delta_4n[1]), _p(delta_4n[2]), _p(delta_4n[3]), _p(out), R, C, V, _stream())
 
 
 def token_embed_bwd(d_out, seqs, deltas, d_table, pad_idx):
@@ -669,3 +694,110 @@ def decode_next_tokens(cls_logits, reg, unfinished_i32, tok_i64, delta, step_i32
     assert cls_logits.numel() == N * 3 and reg.numel() == N * 2 and tok_i64.numel() == 4 * N and delta.numel() == 4 * N
     lib.call("cape_decode_next_tokens", _p(cls_logits), _p(reg), _p(unfinished_i32), _p(tok_i64), _p(delta), _p(step_i32), N,
              num_bins, min_len, eos, sep, pad, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# fused decode step (csrc/decode_step.hip)
+# ------------------------------------------------------------------------------------------------
+def _rows(t, name, width=None):
+    """2-D row view checks for the decode kernels: fp32, unit inner stride, 16-byte aligned rows."""
+    _chk(t, name, contiguous=False)
+    assert t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0, name
+    if width is not None:
+        assert t.shape[1] == width, (name, tuple(t.shape), width)
+    return t
+
+
+def decode_linear(X, W, outs, bias=None, in_ln=None, in_add=None, X2=None, W2=None, res=None, res_ln=None, relu=False):
+    """outs: list of 1..3 (N, seg) row views (any row stride) that tile the Nout = W.shape[0] output columns.
+    in_ln / res_ln: (gamma, beta) -> X / res hold pre-norm sums and are layer-normalised on load."""
+    N, K = X.shape
+    Nout = W.shape[0]
+    _rows(X, "decode_linear.X"); _rows(W, "decode_linear.W", K)
+    assert 1 <= N <= 64 and 1 <= len(outs) <= 3
+    seg = outs[0].shape[1]
+    assert seg * len(outs) == Nout
+    d = lib.DecodeLinearDesc()
+    d.N, d.K, d.Nout = N, K, Nout
+    d.X, d.ldx, d.W, d.ldw = X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0)
+    keep = [X, W]
+    if bias is not None:
+        _chk(bias, "decode_linear.bias"); assert bias.numel() == Nout
+        d.bias = bias.data_ptr()
+    if in_ln is not None:
+        g, b = in_ln
+        _chk(g, "decode_linear.in_gamma"); _chk(b, "decode_linear.in_beta"); assert g.numel() == K and b.numel() == K
+        d.in_gamma, d.in_beta = g.data_ptr(), b.data_ptr()
+    if in_add is not None:
+        _rows(in_add, "decode_linear.in_add", K); assert in_add.shape[0] == N
+        d.in_add, d.ld_add = in_add.data_ptr(), in_add.stride(0)
+    if X2 is not None:
+        _rows(X2, "decode_linear.X2"); _rows(W2, "decode_linear.W2", X2.shape[1]); assert X2.shape[0] == N
+        d.X2, d.ldx2, d.K2, d.W2, d.ldw2, d.n2 = X2.data_ptr(), X2.stride(0), X2.shape[1], W2.data_ptr(), W2.stride(0), W2.shape[0]
+    if res is not None:
+        _rows(res, "decode_linear.res", Nout); assert res.shape[0] == N
+        d.R, d.ldr = res.data_ptr(), res.stride(0)
+        if res_ln is not None:
+            g, b = res_ln
+            _chk(g, "decode_linear.res_gamma"); _chk(b, "decode_linear.res_beta"); assert g.numel() == Nout and b.numel() == Nout
+            d.res_gamma, d.res_beta = g.data_ptr(), b.data_ptr()
+    d.relu, d.nseg, d.seg = int(relu), len(outs), seg
+    for i, o in enumerate(outs):
+        _chk(o, "decode_linear.out", contiguous=False)
+        assert o.dim() == 2 and o.shape == (N, seg) and o.stride(1) == 1
+        assert _avail(o) >= (N - 1) * o.stride(0) + seg
+        d.out[i], d.ldo[i] = o.data_ptr(), o.stride(0)
+    lib.call("cape_decode_linear", ctypes.byref(d), _stream())
+
+
+def decode_tail(P4, ln3, mlp, ref, ref_out, dim_t_, vr=None, cls_head=None, cls_out=None, pos_trans=None, qpos_out=None,
+                refin_out=None, hs_out=None):
+    """mlp = ((W1, b1), (W2, b2), (W3, b3)); cls_head = (Wc, bc) on the last layer; pos_trans = (Wp, bp, gamma, beta) when a
+    next layer exists.  ref (N, 2) contiguous; ref_out / cls_out / hs_out row views (N, 2) / (N, ncls) / (N, 256)."""
+    N = P4.shape[0]
+    _rows(P4, "decode_tail.P4", 256)
+    d = lib.DecodeTailDesc()
+    d.N = N
+    d.P4, d.ldp, d.g3, d.b3 = P4.data_ptr(), P4.stride(0), ln3[0].data_ptr(), ln3[1].data_ptr()
+    (W1, b1), (W2, b2), (W3, b3) = mlp
+    for w in (W1, W2, W3):
+        _chk(w, "decode_tail.W")
+    assert W1.shape == (256, 256) and W2.shape == (256, 256) and W3.shape == (2, 256)
+    d.W1, d.B1, d.W2, d.B2, d.W3, d.B3 = (t.data_ptr() for t in (W1, b1, W2, b2, W3, b3))
+    _chk(ref, "decode_tail.ref"); assert ref.numel() == 2 * N
+    d.ref = ref.data_ptr()
+    assert ref_out.shape == (N, 2) and ref_out.stride(1) == 1
+    d.ref_out, d.ld_ref = ref_out.data_ptr(), ref_out.stride(0)
+    d.L = vr.shape[1] if vr is not None else 1
+    if cls_head is not None:
+        Wc, bc = cls_head
+        _chk(Wc, "decode_tail.Wc"); assert Wc.shape[1] == 256 and cls_out.shape == (N, Wc.shape[0]) and cls_out.stride(1) == 1
+        d.Wc, d.Bc, d.ncls, d.cls_out, d.ld_cls = Wc.data_ptr(), bc.data_ptr(), Wc.shape[0], cls_out.data_ptr(), cls_out.stride(0)
+    if pos_trans is not None:
+        Wp, bp, gp, bpn = pos_trans
+        _chk(Wp, "decode_tail.Wp"); _chk(qpos_out, "decode_tail.qpos_out"); _chk(refin_out, "decode_tail.refin_out"); _chk(vr, "decode_tail.vr")
+        assert Wp.shape == (256, 256) and qpos_out.numel() == N * 256 and refin_out.numel() == N * d.L * 2 and vr.numel() == N * d.L * 2
+        d.Wp, d.Bp, d.gp, d.bp = Wp.data_ptr(), bp.data_ptr(), gp.data_ptr(), bpn.data_ptr()
+        d.dim_t, d.vr, d.qpos_out, d.refin_out = dim_t_.data_ptr(), vr.data_ptr(), qpos_out.data_ptr(), refin_out.data_ptr()
+    if hs_out is not None:
+        _rows(hs_out, "decode_tail.hs_out", 256)
+        d.hs_out, d.ld_hs = hs_out.data_ptr(), hs_out.stride(0)
+    lib.call("cape_decode_tail", ctypes.byref(d), _stream())
+
+
+def decode_advance(cls_slot, reg_slot, unfinished_i32, tok_i64, delta, step, N, num_bins, min_len, eos, sep, pad, table=None,
+                   embed_out=None, alive_out=None):
+    """cls_slot (N, 3) / reg_slot (N, 2) row views (e.g. out_logits[:, i]); see cape_decode_advance."""
+    assert cls_slot.shape == (N, 3) and reg_slot.shape == (N, 2) and cls_slot.stride(1) == 1 and reg_slot.stride(1) == 1
+    _chk(unfinished_i32, "advance.unfinished", dtype=torch.int32); _chk(tok_i64, "advance.tok", dtype=torch.int64); _chk(delta, "advance.delta")
+    assert tok_i64.numel() == 4 * N and delta.numel() == 4 * N and unfinished_i32.numel() == N
+    C = vocab = 0
+    if embed_out is not None:
+        _chk(table, "advance.table"); _chk(embed_out, "advance.embed_out")
+        vocab, C = table.shape
+        assert embed_out.numel() == N * C
+    if alive_out is not None:
+        _chk(alive_out, "advance.alive", dtype=torch.int32, contiguous=False)
+    lib.call("cape_decode_advance", _p(cls_slot), cls_slot.stride(0), _p(reg_slot), reg_slot.stride(0), _p(unfinished_i32),
+             _p(tok_i64), _p(delta), int(step), N, num_bins, min_len, eos, sep, pad, _p(table), vocab, C, _p(embed_out),
+             _p(alive_out), _stream())

@@ -86,7 +86,9 @@ class CAPEModel(nn.Module):
         return outputs
 
     def forward_inference(self, samples, support_coords, support_mask, skeleton_edges=None, max_seq_len=None, use_cache=True,
-                          teacher_stream=None, graph=None):
+                          teacher_stream=None, graph=None, timing=False):
+        """`teacher_stream`, `graph`, `timing` are keyword extras of this implementation (parity tests, hipGraph switch, bench
+        events); the reference signature ends at `use_cache`."""
         if support_mask.dtype != torch.bool:
             support_mask = support_mask.bool()
         encoder_mask = ~support_mask
@@ -95,14 +97,17 @@ class CAPEModel(nn.Module):
         try:
             with torch.no_grad():
                 outputs = self.base_model.forward_inference(samples=samples, use_cache=use_cache, teacher_stream=teacher_stream,
-                                                             graph=graph)
+                                                             graph=graph, timing=timing)
         finally:
             self._clear()
         pred_logits = outputs.get("pred_logits")
         pred_coords = outputs.get("pred_coords")
         # argmax over 3 classes on the host glue side: (N,T,3) -> (N,T) int64 ('sequences' of the reference API)
         pred_tokens = pred_logits.argmax(dim=-1) if pred_logits is not None else None
-        return {"sequences": pred_tokens, "coordinates": pred_coords, "logits": pred_logits}
+        res = {"sequences": pred_tokens, "coordinates": pred_coords, "logits": pred_logits}
+        if timing:
+            res["_timing"] = outputs.get("_timing")
+        return res
 
 
 def build_cape_model(args, base_model):

@@ -94,11 +94,14 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, src_pos, pos, reference_points, geo, padding_rows_u8=None):
         """src (N,S,256), src_pos = src + pos.  Returns (new_src, new_src + pos)."""
         p = self.dropout1.p if self.training else 0.0
-        a = self.self_attn(src_pos, reference_points, src, geo, padding_rows_u8)
-        src = HF.add_layernorm(src, a, self.norm1.weight, self.norm1.bias, dropout_p=p, rng_stream=self._streams[0])
-        h = HF.ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, dropout_p=p,
+        # every tensor with two consumers goes through HF.fanout: its gradients are summed by one HIP launch, not by autograd
+        src_v, src_r = HF.fanout(src, 2)
+        a = self.self_attn(src_pos, reference_points, src_v, geo, padding_rows_u8)
+        src = HF.add_layernorm(src_r, a, self.norm1.weight, self.norm1.bias, dropout_p=p, rng_stream=self._streams[0])
+        src_f, src_r = HF.fanout(src, 2)
+        h = HF.ffn(src_f, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, dropout_p=p,
                    rng_stream=self._streams[1])
-        return HF.add_layernorm(src, h, self.norm2.weight, self.norm2.bias, pos=pos, dropout_p=p, rng_stream=self._streams[2])
+        return HF.add_layernorm(src_r, h, self.norm2.weight, self.norm2.bias, pos=pos, dropout_p=p, rng_stream=self._streams[2])
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -126,8 +129,9 @@ class DeformableTransformerEncoder(nn.Module):
     def forward(self, src, geo, valid_ratios, pos, padding_rows_u8=None):
         with torch.no_grad():
             reference_points = self.get_reference_points(geo, valid_ratios, src.device)
-        output = src
-        out_pos = HF.add(src, pos)
-        for layer in self.layers:
-            output, out_pos = layer(output, out_pos, pos, reference_points, geo, padding_rows_u8)
+        poss = HF.fanout(pos, len(self.layers) + 1)
+        output, src0 = HF.fanout(src, 2)
+        out_pos = HF.add(src0, poss[0])
+        for layer, pos_l in zip(self.layers, poss[1:]):
+            output, out_pos = layer(output, out_pos, pos_l, reference_points, geo, padding_rows_u8)
         return output

@@ -76,26 +76,32 @@ class TransformerDecoderLayer(nn.Module):
         """Teacher-forced pass over the whole sequence (causal mask)."""
         p = self.dropout2.p if self.training else 0.0
         st = self._streams
-        q = HF.linear(tgt, self.attn_q.weight, residual=query_pos)
-        k = HF.linear(tgt, self.attn_k.weight)
-        v = HF.linear(tgt, self.attn_v.weight)
+        # tensors with several consumers go through HF.fanout (one HIP launch sums their gradients)
+        t_q, t_k, t_v, t_r = HF.fanout(tgt, 4)
+        qp_q, qp_s = HF.fanout(query_pos, 2)
+        q = HF.linear(t_q, self.attn_q.weight, residual=qp_q)
+        k = HF.linear(t_k, self.attn_k.weight)
+        v = HF.linear(t_v, self.attn_v.weight)
         sa = self.self_attn
         t2 = HF.mha(q, k, v, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.n_heads,
                     mask_mode=1, dropout_p=p, rng_stream=st[0])
-        tgt = HF.add_layernorm(tgt, t2, self.norm2.weight, self.norm2.bias, dropout_p=p, rng_stream=st[1])
+        tgt = HF.add_layernorm(t_r, t2, self.norm2.weight, self.norm2.bias, dropout_p=p, rng_stream=st[1])
         if support_features is not None:
             ca = self.support_attn
-            t2 = HF.mha(tgt, support_features, support_features, ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight,
+            t_q, t_r = HF.fanout(tgt, 2)
+            t2 = HF.mha(t_q, support_features, support_features, ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight,
                         ca.out_proj.bias, self.n_heads, mask_mode=2 if support_kpm_u8 is not None else 0,
                         kpm_u8=support_kpm_u8, dropout_p=p, rng_stream=st[2])
-            tgt, tgt_pos = HF.add_layernorm(tgt, t2, self.norm_support.weight, self.norm_support.bias, pos=query_pos,
+            tgt, tgt_pos = HF.add_layernorm(t_r, t2, self.norm_support.weight, self.norm_support.bias, pos=qp_s,
                                             dropout_p=p, rng_stream=st[3])
         else:
-            tgt_pos = HF.add(tgt, query_pos)
+            tgt, t_r = HF.fanout(tgt, 2)
+            tgt_pos = HF.add(t_r, qp_s)
         t2 = self.cross_attn(tgt_pos, reference_points, src, geo, padding_rows_u8)
         tgt = HF.add_layernorm(tgt, t2, self.norm1.weight, self.norm1.bias, dropout_p=p, rng_stream=st[4])
-        h = HF.ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, dropout_p=p, rng_stream=st[5])
-        return HF.add_layernorm(tgt, h, self.norm3.weight, self.norm3.bias, dropout_p=p, rng_stream=st[6])
+        t_f, t_r = HF.fanout(tgt, 2)
+        h = HF.ffn(t_f, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, dropout_p=p, rng_stream=st[5])
+        return HF.add_layernorm(t_r, h, self.norm3.weight, self.norm3.bias, dropout_p=p, rng_stream=st[6])
 
     # ---- cached single-token step (inference only) -------------------------------------------------
     @torch.no_grad()
@@ -202,14 +208,19 @@ class TransformerDecoder(nn.Module):
                                  seq22=seq_kwargs["seq22"], delta_x1=seq_kwargs["delta_x1"], delta_x2=seq_kwargs["delta_x2"],
                                  delta_y1=seq_kwargs["delta_y1"], delta_y2=seq_kwargs["delta_y2"])
         hs, refs, clss = [], [], []
+        nl = len(self.layers)
+        mems = HF.fanout(src, nl)                                       # the image memory feeds every layer's value projection
+        sups = HF.fanout(support_features, nl) if support_features is not None else (None,) * nl
         for lid, layer in enumerate(self.layers):
-            ref_in = HF.ref_scale(reference_points, src_valid_ratios)
-            query_pos = self._query_pos(reference_points)
-            output = layer(output, query_pos, ref_in, src, geo, padding_rows_u8, support_features, kpm)
-            delta = self._mlp(self.coords_embed[lid], output)
-            reference_points = HF.refine(delta, reference_points)       # no detach between layers (:1096-1102)
-            cls = HF.linear(output, self.class_embed[lid].weight, self.class_embed[lid].bias)
-            hs.append(output); refs.append(reference_points); clss.append(cls)
+            r_scale, r_sine, r_ref = HF.fanout(reference_points, 3)
+            ref_in = HF.ref_scale(r_scale, src_valid_ratios)
+            query_pos = self._query_pos(r_sine)
+            output = layer(output, query_pos, ref_in, mems[lid], geo, padding_rows_u8, sups[lid], kpm)
+            o_mlp, o_cls, o_hs, output = HF.fanout(output, 4)
+            delta = self._mlp(self.coords_embed[lid], o_mlp)
+            reference_points, r_keep = HF.fanout(HF.refine(delta, r_ref), 2)   # no detach between layers (:1096-1102)
+            cls = HF.linear(o_cls, self.class_embed[lid].weight, self.class_embed[lid].bias)
+            hs.append(o_hs); refs.append(r_keep); clss.append(cls)
         return torch.stack(hs), torch.stack(refs), torch.stack(clss)
 
     @torch.no_grad()
@@ -237,6 +248,119 @@ class TransformerDecoder(nn.Module):
         cls = torch.empty(N, ce.weight.shape[0], dtype=torch.float32, device=ref.device)
         ops.gemm(output.view(N, 256), ce.weight, cls, N, ce.weight.shape[0], 256, bias=ce.bias)
         return output, ref, cls
+
+
+# ------------------------------------------------------------------------------------------------
+# fused cached decode step (csrc/decode_step.hip): ~12 launches per layer, LayerNorms applied on load
+# ------------------------------------------------------------------------------------------------
+def _fold(w_in, w_a):
+    """(w_in @ w_a) on the device in exact fp32: the two chained projections of the decoder's self-attention
+    (attn_x then MultiheadAttention.in_proj, deformable_transformer_v2.py:323-331) as one weight for inference."""
+    out = torch.empty(w_in.shape[0], w_a.shape[1], dtype=torch.float32, device=w_in.device)
+    old = ops.get_gemm_precision()
+    ops.set_gemm_precision("f32")
+    try:
+        ops.gemm(w_in, w_a, out, w_in.shape[0], w_a.shape[1], w_in.shape[1], a_mode=0, b_mode=1, ldb=w_a.stride(0))
+    finally:
+        ops.set_gemm_precision(old)
+    return out
+
+
+class DecodeWeights:
+    """Inference-time weights of the fused decode step, rebuilt when any source parameter changed
+    (version counter or storage): per layer the folded q|k|v projection (768 x 256) and the concatenated
+    sampling_offsets|attention_weights projection (384 x 256)."""
+
+    def __init__(self, decoder):
+        self.decoder, self.key, self.layers = decoder, None, None
+
+    def _sources(self):
+        out = []
+        for l in self.decoder.layers:
+            m = l.cross_attn
+            out += [l.attn_q.weight, l.attn_k.weight, l.attn_v.weight, l.self_attn.in_proj_weight, m.sampling_offsets.weight,
+                    m.sampling_offsets.bias, m.attention_weights.weight, m.attention_weights.bias]
+        return out
+
+    def get(self):
+        key = tuple((t.data_ptr(), t._version) for t in self._sources())
+        if key != self.key:
+            C = self.decoder.layers[0].d_model
+            layers = []
+            with torch.no_grad():
+                for l in self.decoder.layers:
+                    W = l.self_attn.in_proj_weight
+                    m = l.cross_attn
+                    layers.append({
+                        "w_qkv": torch.cat([_fold(W[:C], l.attn_q.weight), _fold(W[C:2 * C], l.attn_k.weight),
+                                            _fold(W[2 * C:], l.attn_v.weight)], 0).contiguous(),
+                        "w_off": torch.cat([m.sampling_offsets.weight, m.attention_weights.weight], 0).contiguous(),
+                        "b_off": torch.cat([m.sampling_offsets.bias, m.attention_weights.bias], 0).contiguous()})
+            self.layers, self.key = layers, key
+        return self.layers
+
+
+def alloc_decode_workspace(N, n_layers, L, dev):
+    """Static per-geometry buffers of the fused step (pre-norm sums p1..p4, projections, per-layer query positions)."""
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    return {"emb": f(N, 256), "q": f(N, 256), "qs": f(N, 256), "p1": f(N, 256), "p2": f(N, 256), "p3": f(N, 256),
+            "p4": [f(N, 256) for _ in range(n_layers)], "offw": f(N, 384), "h": f(N, 1024),
+            "qpos": [None] + [f(N, 256) for _ in range(n_layers - 1)], "refin": [None] + [f(N, L, 2) for _ in range(n_layers - 1)],
+            "ref": [None] + [f(N, 2) for _ in range(n_layers)]}
+
+
+@torch.no_grad()
+def decode_step_fused(decoder, dw, ws, caches, geo, vr, step, qpos0, refin0, ref0, out_logits, out_coords, out_hs):
+    """One cached AR step for N images.  ws["emb"] holds the embedding of the step's input tokens; layer 0's query
+    position embedding / level-scaled points / reference come from per-call tables (qpos0 (256,) broadcast over rows,
+    refin0 (N, L, 2), ref0 (N, 2)), the later layers' from the previous layer's tail kernel.  Writes the step's class
+    logits, refined coordinates and last hidden state into slot `step` of the output buffers."""
+    layers = decoder.layers
+    nl = len(layers)
+    N = ws["emb"].shape[0]
+    C, H = 256, layers[0].n_heads
+    scale = (C // H) ** -0.5
+    dim_t = ops.dim_t(ws["emb"].device)
+    x_prev, ln_prev = ws["emb"], None                       # input of the layer as (pre-norm rows, LayerNorm to apply on load)
+    for l, (layer, w, c) in enumerate(zip(layers, dw, caches)):
+        qpos = qpos0.view(1, C).expand(N, C) if l == 0 else ws["qpos"][l]
+        refin = refin0 if l == 0 else ws["refin"][l]
+        ref = ref0 if l == 0 else ws["ref"][l]
+        sa = layer.self_attn
+        # q | k | v in one launch (folded projections; `+ query_pos` through in_proj_q), k / v straight into the cache row
+        ops.decode_linear(x_prev, w["w_qkv"], [ws["q"], c["k"][:, step], c["v"][:, step]], bias=sa.in_proj_bias, in_ln=ln_prev,
+                          X2=qpos, W2=sa.in_proj_weight[:C])
+        a, _ = ops.attn_fwd(ws["q"].view(N, 1, C), c["k"], c["v"], N, H, 1, step + 1, scale, mask_mode=0)
+        ops.decode_linear(a.view(N, C), sa.out_proj.weight, [ws["p1"]], bias=sa.out_proj.bias, res=x_prev, res_ln=ln_prev)
+        ln2 = (layer.norm2.weight, layer.norm2.bias)
+        if c.get("sup_k") is not None:
+            ca = layer.support_attn
+            ops.decode_linear(ws["p1"], ca.in_proj_weight[:C], [ws["qs"]], bias=ca.in_proj_bias[:C], in_ln=ln2)
+            P = c["sup_k"].shape[1]
+            a2, _ = ops.attn_fwd(ws["qs"].view(N, 1, C), c["sup_k"], c["sup_v"], N, H, 1, P, scale,
+                                 mask_mode=2 if c["sup_kpm"] is not None else 0, kpm=c["sup_kpm"])
+            ops.decode_linear(a2.view(N, C), ca.out_proj.weight, [ws["p2"]], bias=ca.out_proj.bias, res=ws["p1"], res_ln=ln2)
+            t_pre, t_ln = ws["p2"], (layer.norm_support.weight, layer.norm_support.bias)
+        else:
+            t_pre, t_ln = ws["p1"], ln2
+        m = layer.cross_attn
+        ops.decode_linear(t_pre, w["w_off"], [ws["offw"]], bias=w["b_off"], in_ln=t_ln, in_add=qpos)
+        g = ops.msda_fwd(c["value"], ws["offw"].view(N, 1, -1), refin.view(N, 1, geo.L, 2), geo, N, 1, m.n_points)
+        ops.decode_linear(g.view(N, C), m.output_proj.weight, [ws["p3"]], bias=m.output_proj.bias, res=t_pre, res_ln=t_ln)
+        ln1 = (layer.norm1.weight, layer.norm1.bias)
+        ops.decode_linear(ws["p3"], layer.linear1.weight, [ws["h"]], bias=layer.linear1.bias, in_ln=ln1, relu=True)
+        ops.decode_linear(ws["h"], layer.linear2.weight, [ws["p4"][l]], bias=layer.linear2.bias, res=ws["p3"], res_ln=ln1)
+        ln3 = (layer.norm3.weight, layer.norm3.bias)
+        mlp = tuple((q.weight, q.bias) for q in decoder.coords_embed[l].layers)
+        last = l == nl - 1
+        ops.decode_tail(ws["p4"][l], ln3, mlp, ref, out_coords[:, step] if last else ws["ref"][l + 1], dim_t, vr=vr,
+                        cls_head=(decoder.class_embed[l].weight, decoder.class_embed[l].bias) if last else None,
+                        cls_out=out_logits[:, step] if last else None,
+                        pos_trans=None if last else (decoder.pos_trans.weight, decoder.pos_trans.bias, decoder.pos_trans_norm.weight,
+                                                     decoder.pos_trans_norm.bias),
+                        qpos_out=None if last else ws["qpos"][l + 1], refin_out=None if last else ws["refin"][l + 1],
+                        hs_out=out_hs[:, step] if last else None)
+        x_prev, ln_prev = ws["p4"][l], ln3
 
 
 class DeformableTransformer(nn.Module):

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from ..util import misc as utils
+from ..util.checkpoint import load_checkpoint, rng_restore, rng_snapshot
 from ..util.eval_utils import PCKEvaluator
 from ..hip import functional as HF
 
@@ -45,8 +46,9 @@ def train_one_epoch_episodic(model: torch.nn.Module, criterion: torch.nn.Module,
                              print_freq: int = 10, accumulation_steps: int = 1, scaler=None, ddp=None):
     """One epoch of episodic training with gradient accumulation.  `optimizer` is an `ArenaAdamW`
     (clipping happens inside its fused step; `max_norm` is forwarded to it); `ddp` an optional
-    `EpisodeDataParallel`.  `scaler` must be None: the MI355X path computes in exact fp32 (the parity bar
-    of 1e-3 on logits rules out fp16/bf16 autocast)."""
+    `EpisodeDataParallel`.  `scaler` must be None: the MI355X path keeps fp32 storage and accumulation, with the GEMMs as a
+    bf16x3 split by default (CAPE_GEMM_PRECISION=f32 selects exact fp32 MFMA); plain fp16/bf16 autocast misses the parity
+    bar of 1e-3 on logits."""
     if scaler is not None:
         raise ValueError("AMP is not available on the MI355X path (fp32 MFMA); run without --use_amp")
     model.train()
@@ -289,7 +291,7 @@ def run_training(args):
     lr_scheduler = build_scheduler(optimizer, args, steps_per_epoch=len(train_loader))
     best_pck, no_improve = 0.0, 0
     if args.resume:
-        ck = torch.load(args.resume, map_location="cpu", weights_only=False)      # our own checkpoint format
+        ck = load_checkpoint(args.resume)           # weights_only loader (util/checkpoint.py): nothing in the file is executed
         model.load_state_dict(ck["model"], strict=False)
         if "optimizer" in ck:
             optimizer.load_state_dict(ck["optimizer"])
@@ -297,8 +299,7 @@ def run_training(args):
             lr_scheduler.load_state_dict(ck["lr_scheduler"])
         args.start_epoch = ck.get("epoch", -1) + 1
         best_pck, no_improve = ck.get("best_pck", 0.0), ck.get("epochs_without_improvement", 0)
-        if "rng_state" in ck:
-            torch.set_rng_state(ck["rng_state"]); np.random.set_state(ck["np_rng_state"]); random.setstate(ck["py_rng_state"])
+        rng_restore(ck, HF.Runtime.get_rng(device))   # host generators, torch's device generators and the HIP dropout counter
     history = []
     for epoch in range(args.start_epoch, args.epochs):
         if sampler is not None:
@@ -318,9 +319,7 @@ def run_training(args):
                     f"qpe{args.num_queries_per_episode}.pth")
             ck = {"model": model.state_dict(), "optimizer": optimizer.state_dict(), "lr_scheduler": lr_scheduler.state_dict(),
                   "scaler": None, "epoch": epoch, "args": args, "train_stats": train_stats, "val_stats": val_stats,
-                  "best_pck": best_pck, "epochs_without_improvement": no_improve, "rng_state": torch.get_rng_state(),
-                  "np_rng_state": np.random.get_state(), "py_rng_state": random.getstate(),
-                  "cuda_rng_state": torch.cuda.get_rng_state_all()}
+                  "best_pck": best_pck, "epochs_without_improvement": no_improve, **rng_snapshot(HF.Runtime.get_rng(device))}
             torch.save(ck, Path(args.output_dir) / name)
             cleanup_old_checkpoints(args.output_dir, "checkpoint_e*.pth", 3, "best")
         pck_now, pck_mean = val_stats.get("pck", 0.0), val_stats.get("pck_mean_categories", 0.0)

@@ -64,12 +64,14 @@ class GeometricSupportEncoder(nn.Module):
         p = self.dropout_p if self.training else 0.0
         for li, layer in enumerate(self.transformer_encoder.layers):
             sa, st = layer.self_attn, self._streams[li]
-            a = HF.mha(x, x, x, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.nhead,
+            x_a, x_r = HF.fanout(x, 2)              # attention input (q = k = v: one accumulated gradient) | residual
+            a = HF.mha(x_a, x_a, x_a, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.nhead,
                        mask_mode=2, kpm_u8=kpm, dropout_p=p, rng_stream=st[0])
-            x = HF.add_layernorm(x, a, layer.norm1.weight, layer.norm1.bias, dropout_p=p, rng_stream=st[1])
-            hdn = HF.ffn(x, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, dropout_p=p,
+            x = HF.add_layernorm(x_r, a, layer.norm1.weight, layer.norm1.bias, dropout_p=p, rng_stream=st[1])
+            x_f, x_r = HF.fanout(x, 2)
+            hdn = HF.ffn(x_f, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, dropout_p=p,
                          rng_stream=st[2])
-            x = HF.add_layernorm(x, hdn, layer.norm2.weight, layer.norm2.bias, dropout_p=p, rng_stream=st[3])
+            x = HF.add_layernorm(x_r, hdn, layer.norm2.weight, layer.norm2.bias, dropout_p=p, rng_stream=st[3])
         zero = all_masked[:, None].expand(bs, num_pts)
         if fast:
             zero = zero | mask

@@ -15,7 +15,8 @@ from ..hip import functional as HF
 from ..hip import ops
 from ..util.misc import NestedTensor, nested_tensor_from_tensor_list
 from .backbone import Conv2dCL, build_backbone
-from .deformable_transformer_v2 import build_deforamble_transformer
+from .deformable_transformer_v2 import (DecodeWeights, alloc_decode_workspace, build_deforamble_transformer, decode_step_fused)
+from .kv_cache import KVCache, VCache
 
 
 def _get_clones(module, N):
@@ -156,7 +157,7 @@ class RoomFormerV2(nn.Module):
     # ---- KV-cached autoregressive inference -------------------------------------------------------
     @torch.no_grad()
     def forward_inference(self, samples, use_cache=True, support_graphs=None, support_mask=None, sync_every=8,
-                          teacher_stream=None, graph=None):
+                          teacher_stream=None, graph=None, timing=False):
         """Generates until every sample has emitted <eos> (after >= 6 steps) or `tokenizer.seq_len` steps.
         Token bookkeeping (roomformer_v2.py:521-598) runs on the device; the host only polls the
         `unfinished` flags every `sync_every` steps, then trims to the step at which the reference's loop
@@ -173,6 +174,8 @@ class RoomFormerV2(nn.Module):
         if graph is None:
             graph = os.environ.get("CAPE_DECODE_GRAPH", "1") == "1"
         graph = graph and teacher_stream is None
+        # fused step (csrc/decode_step.hip): ~75 launches instead of ~190; CAPE_DECODE_FUSED=0 keeps the per-op step for A/B
+        fused = os.environ.get("CAPE_DECODE_FUSED", "1") == "1" and memory_rows_ok(samples)
         enc = self._encode_images(samples)
         dec = self.transformer.decoder
         geo, vr, memory = enc["geo"], enc["valid_ratios"], enc["memory"]
@@ -185,7 +188,8 @@ class RoomFormerV2(nn.Module):
         P = support.shape[1] if support is not None else 0
 
         # ---- state buffers (static per geometry when graphs are used) ----
-        key = (N, tuple(geo.shapes), P, smask is not None, max_len, str(dev), ops.get_gemm_precision())
+        fused = fused and N <= 64
+        key = (N, tuple(geo.shapes), P, smask is not None, max_len, str(dev), ops.get_gemm_precision(), fused)
         st = self._decode_states.get(key) if graph else None
         fresh = st is None
         if fresh:
@@ -195,12 +199,22 @@ class RoomFormerV2(nn.Module):
                   "unfinished": torch.empty(N, dtype=torch.int32, device=dev), "step_t": torch.zeros(1, dtype=torch.int32, device=dev),
                   "out_logits": torch.zeros(N, max_len, self.num_classes, device=dev), "out_coords": torch.zeros(N, max_len, 2, device=dev),
                   "out_hs": torch.zeros(N, max_len, 256, device=dev), "alive_after": torch.zeros(max_len, dtype=torch.int32, device=dev),
-                  "caches": [{"k": torch.zeros(N, self.seq_len, 256, device=dev), "v": torch.zeros(N, self.seq_len, 256, device=dev),
-                              "value": torch.empty(N, geo.S, 256, device=dev),
-                              "sup_k": torch.empty(N, P, 256, device=dev) if P else None,
-                              "sup_v": torch.empty(N, P, 256, device=dev) if P else None,
-                              "sup_kpm": torch.empty(N, P, dtype=torch.uint8, device=dev) if (P and smask is not None) else None}
-                             for _ in dec.layers]}
+                  # the reference's cache modules (kv_cache.py): K / V slabs (N, seq_len, 256) written in place at row `step`
+                  # (here: post-projection rows), VCache = the per-layer MSDA value projection of the image memory
+                  "kv": [KVCache(N, self.seq_len, 256, torch.float32).to(dev) for _ in dec.layers],
+                  "vc": [VCache(N, geo.S, self.transformer.nhead, 256 // self.transformer.nhead, torch.float32).to(dev) for _ in dec.layers]}
+            st["caches"] = [{"k": kv.k_cache, "v": kv.v_cache, "value": vc.v_cache.view(N, geo.S, 256),
+                             "sup_k": torch.empty(N, P, 256, device=dev) if P else None,
+                             "sup_v": torch.empty(N, P, 256, device=dev) if P else None,
+                             "sup_kpm": torch.empty(N, P, dtype=torch.uint8, device=dev) if (P and smask is not None) else None}
+                            for kv, vc in zip(st["kv"], st["vc"])]
+            if fused:
+                st["ws"] = alloc_decode_workspace(N, len(dec.layers), geo.L, dev)
+                st["alive_i32"] = torch.zeros(max_len, dtype=torch.int32, device=dev)
+                # layer-0 tables (static storage: captured step graphs hold pointers into them)
+                st["qpos0"] = torch.empty(self.query_embed.weight.shape[0], 256, device=dev)
+                st["ref0"] = torch.empty(max_len, N, 2, device=dev)
+                st["refin0"] = torch.empty(max_len, N, geo.L, 2, device=dev)
             if graph:
                 if len(self._decode_states) >= 4:
                     self._decode_states.pop(next(iter(self._decode_states)))
@@ -213,6 +227,8 @@ class RoomFormerV2(nn.Module):
             st["calls"] = 0
         st["calls"] += 1
         caches = st["caches"]
+        for layer, kv, vc in zip(dec.layers, st["kv"], st["vc"]):      # the modules the reference's _setup_caches installs
+            layer.kv_cache, layer.cross_attn.cache = kv, vc
         for layer, c in zip(dec.layers, caches):
             c["value"].copy_(layer.cross_attn.project_value(memory, enc["pad_rows"]))
             if P:
@@ -240,7 +256,41 @@ class RoomFormerV2(nn.Module):
                                    tok.eos, tok.sep, tok.pad)
             alive_after[i] = unfinished.sum()
 
+        if fused:
+            # per-call tables of layer 0 (its reference points are the learned anchors, the same for every image):
+            # query position embedding per step, level-scaled points and the (N, 2) reference rows the tail kernel refines
+            if getattr(self, "_decode_weights", None) is None:
+                self._decode_weights = DecodeWeights(dec)
+            dw = self._decode_weights.get()
+            T0 = ref_all.shape[0]
+            qs0 = ops.query_sine_fwd(ref_all)
+            qp0 = torch.empty(T0, 256, device=dev)
+            ops.gemm(qs0, dec.pos_trans.weight, qp0, T0, 256, 256, bias=dec.pos_trans.bias)
+            qp0, _, _, _ = ops.add_layernorm_fwd(qp0, None, dec.pos_trans_norm.weight, dec.pos_trans_norm.bias)
+            st["qpos0"].copy_(qp0)
+            st["ref0"].copy_(ref_all[:max_len, None, :].expand(max_len, N, 2))
+            st["refin0"].copy_(ops.ref_scale_fwd(st["ref0"].view(-1, 2), vr_s.repeat(max_len, 1, 1).contiguous(), 1, geo.L).view(max_len, N, geo.L, 2))
+            wsb = st["ws"]
+            ops.token_embed_fwd_into(dec.token_embed.weight, toks, deltas, wsb["emb"])
+            alive_i32 = st["alive_i32"]
+            alive_i32.zero_()
+
+            def step_body(i, toks_i, deltas_i):
+                if toks_i is not toks:                       # teacher forcing: the step's input tokens come from the stream
+                    ops.token_embed_fwd_into(dec.token_embed.weight, toks_i, deltas_i, wsb["emb"])
+                decode_step_fused(dec, dw, wsb, caches, geo, vr_s, i, st["qpos0"][i], st["refin0"][i], st["ref0"][i], out_logits,
+                                  out_coords, out_hs)
+                if toks_i is toks:
+                    ops.decode_advance(out_logits[:, i], out_coords[:, i], unfinished, toks, deltas, i, N, tok.num_bins, min_len,
+                                       tok.eos, tok.sep, tok.pad, table=dec.token_embed.weight, embed_out=wsb["emb"],
+                                       alive_out=alive_i32[i:i + 1])
+            alive_after = alive_i32
+
         use_graphs = graph and st["calls"] >= 2            # call 1 of a geometry: eager (also the warm-up the capture needs)
+        ev_loop0 = ev_loop1 = None
+        if timing:                                          # bench.py: the decode loop alone (image encoding excluded)
+            ev_loop0, ev_loop1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_loop0.record()
         i, T = 0, max_len
         while i < max_len:
             if teacher_stream is not None:
@@ -253,7 +303,7 @@ class RoomFormerV2(nn.Module):
                     g = torch.cuda.CUDAGraph()
                     if st["pool"] is None:
                         st["pool"] = torch.cuda.graph_pool_handle()
-                    with torch.cuda.graph(g, pool=st["pool"]):
+                    with torch.cuda.graph(g, pool=st["pool"], capture_error_mode="thread_local"):    # DataLoader pin-memory threads may call hipHostMalloc meanwhile
                         step_body(i, toks, deltas)
                     st["graphs"][i] = g
                 g.replay()
@@ -269,11 +319,15 @@ class RoomFormerV2(nn.Module):
         else:
             T = i
         T = min(T, i)
+        if timing:
+            ev_loop1.record()
         incomplete = int(unfinished.sum()) if teacher_stream is None else 0
         if incomplete > 0 and os.environ.get("WARN_INCOMPLETE_GENERATION", "1") == "1":
             warnings.warn(f"{incomplete}/{N} sequences reached max_len={max_len} without predicting EOS.")
         # the state buffers are reused by the next call: hand out copies
         out = {"pred_logits": out_logits[:, :T].clone(), "pred_coords": out_coords[:, :T].clone(), "gen_out": None}
+        if timing:
+            out["_timing"] = {"events": (ev_loop0, ev_loop1), "steps_run": i, "launch": "graph" if use_graphs else "eager", "fused": fused}
         if self.room_class_embed is not None:
             hs2 = out_hs[:, :T].contiguous()
             rl = torch.empty(N, T, self.room_class_embed.weight.shape[0], device=dev)
@@ -286,6 +340,12 @@ class RoomFormerV2(nn.Module):
     def _setup_caches(self, max_bs, max_src_len):
         self.transformer._setup_caches(max_bs, self.seq_len, max_src_len, self.transformer.d_model, self.transformer.nhead,
                                        self.transformer.level_embed.dtype, device=self.transformer.level_embed.device)
+
+
+def memory_rows_ok(samples):
+    """The fused decode kernels take at most 64 token rows (images in flight) per launch."""
+    n = samples.tensors.shape[0] if isinstance(samples, NestedTensor) else (samples.shape[0] if isinstance(samples, torch.Tensor) else len(samples))
+    return n <= 64
 
 
 def _nearest_mask(mask, h, w):

@@ -9,7 +9,12 @@ is the MI355X-native design for it:
     fully-connected xGMI node RCCL moves 1/8 of a bucket over each of the 7 links concurrently, and 25 MB
     keeps each launch in the bandwidth regime while leaving several buckets to overlap with backward;
   * a bucket is launched on a side stream as soon as the last of its parameters has accumulated its
-    gradient (post-accumulate-grad hooks); `finish()` joins the stream before the optimizer step;
+    gradient (post-accumulate-grad hooks, or -- for weight gradients that kernels accumulate straight into the arena --
+    one notification per *use*: a parameter applied several times in the forward, e.g. the decoder's shared `pos_trans`,
+    is complete only after as many notifications as the calibration step counted); `finish()` joins the stream before
+    the optimizer step;
+  * every rank must launch the same bucket sequence (collectives match by order): the sequence of the first steps is
+    compared across ranks (`check_order_steps`), and `stats` reports bytes reduced and the exposed communication time;
   * micro-batches of gradient accumulation skip the exchange (`no_sync`), the boundary micro-batch reduces
     the accumulated sum;
   * parameters that never receive gradients are outside the arenas, identically on all ranks.
@@ -23,8 +28,13 @@ from ..hip import functional as HF
 
 
 class EpisodeDataParallel:
-    def __init__(self, model, optimizer, bucket_mb=25.0, process_group=None):
+    def __init__(self, model, optimizer, bucket_mb=25.0, process_group=None, check_order_steps=2):
         self.model, self.opt, self.pg = model, optimizer, process_group
+        self.check_order_steps = check_order_steps      # compare the bucket launch order across ranks on the first steps
+        self.steps_done = 0
+        self.stats = {"steps": 0, "bytes_per_step": 0, "exposed_ms": 0.0, "launch_order": []}
+        self._uses = {}             # id(param) -> notifications per backward (calibrated on the first exchanged step)
+        self._calibrated = False
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.sync_enabled = True
         self.buckets = []           # (arena, lo, hi, [param indices])
@@ -75,13 +85,22 @@ class EpisodeDataParallel:
         self._reset_pending()
 
     def _on_direct_grad(self, p):
+        """One call per weight-gradient launch into the arena.  A parameter used k times in the forward gets k launches;
+        its bucket may go only after the k-th (the others are still accumulating into the same slot on the side stream)."""
         bi = self._bucket_of.get(id(p))
         if bi is None or not self.sync_enabled:
             return
-        key = (bi, id(p))
-        if key in self._seen:
-            return                                  # a parameter used twice in one backward counts once
-        self._seen.add(key)
+        self._count[id(p)] = self._count.get(id(p), 0) + 1
+        if not self._calibrated:
+            return                                  # calibration step: count uses, buckets go in finish()
+        need = self._uses.get(id(p))
+        if need is None or self._count[id(p)] > need:
+            self._calibrated = False                # a use pattern never seen: fall back to finish() and recount
+            return
+        if self._count[id(p)] == need:
+            self._param_done(bi)
+
+    def _param_done(self, bi):
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
@@ -90,6 +109,8 @@ class EpisodeDataParallel:
         self._pending = {bi: len(b[3]) for bi, b in enumerate(self.buckets)}
         self._launched = set()
         self._seen = set()
+        self._count = {}
+        self._order = []
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -97,17 +118,18 @@ class EpisodeDataParallel:
                 return
             key = (bi, id(_p))
             if key in self._seen:
-                return
+                return                              # autograd accumulates a parameter's gradient once per backward
             self._seen.add(key)
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self._launch(bi)
+            self._count[id(_p)] = 1
+            if self._calibrated and self._uses.get(id(_p)) == 1:
+                self._param_done(bi)
         return hook
 
     def _launch(self, bi):
         if bi in self._launched:
             return
         self._launched.add(bi)
+        self._order.append(bi)
         a, lo, hi, _ = self.buckets[bi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -131,14 +153,46 @@ class EpisodeDataParallel:
         gradient was not produced this step still hold their zeros) and joins the communication."""
         if self.world < 2:
             return
+        ev0 = ev1 = None
+        if self.comm_stream is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev0.record()          # backward fully enqueued on the main stream
         for bi in range(len(self.buckets)):
             self._launch(bi)
         if self.comm_stream is not None:
+            ev1 = torch.cuda.Event(enable_timing=True); ev1.record(self.comm_stream)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         for h in self._handles:
             h.wait()
         self._handles = []
+        # use counts of this step become the expectation of the next ones (identical on every rank as long as no rank
+        # takes a data-dependent branch; a mismatch shows up in the order check below)
+        if not self._calibrated:
+            self._uses = dict(self._count)
+            self._calibrated = True
+        elif any(self._count.get(k, 0) != v for k, v in self._uses.items()):
+            self._uses, self._calibrated = dict(self._count), True
+        order = list(self._order)
+        if self.steps_done < self.check_order_steps:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, order, group=self.pg)
+            if any(g != gathered[0] for g in gathered):
+                raise RuntimeError(f"data-parallel ranks launched their gradient buckets in different orders: {gathered}")
+        self.steps_done += 1
+        st = self.stats
+        st["steps"] += 1
+        st["bytes_per_step"] = sum(4 * (hi - lo) for _, lo, hi, _ in self.buckets)
+        st["launch_order"] = order
+        if ev0 is not None:
+            st["_events"] = (ev0, ev1)              # read lazily: elapsed_time needs both events complete
         self._reset_pending()
+
+    def exposed_comm_ms(self):
+        """Time the last step's communication ran past the end of its backward (0 = fully overlapped).  Synchronises."""
+        ev = self.stats.get("_events")
+        if ev is None:
+            return 0.0
+        ev[1].synchronize()
+        return max(0.0, ev[0].elapsed_time(ev[1]))
 
     @property
     def loss_scale(self):

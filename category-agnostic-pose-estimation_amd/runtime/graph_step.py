@@ -64,7 +64,7 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         HF.Runtime.capture_keep = []
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):    # other threads (pin-memory workers) stay free to call HIP
                 losses = self._eager(s_in[0], s_in[1], s_in[2], s_tg, s_sk)
             keep = HF.Runtime.capture_keep
         finally:

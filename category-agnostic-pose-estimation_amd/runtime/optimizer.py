@@ -2,7 +2,11 @@
 (`cape_sumsq` + `cape_adamw_step`).  Semantics of `torch.optim.AdamW(param_dicts, lr, weight_decay)` after
 `torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)` (reference
 `train_cape_episodic.py:527-538`, `engine_cape.py:240-258`).  Exposes `param_groups` (lr schedulers work),
-`step`, `zero_grad`, `state_dict`/`load_state_dict` in torch's per-parameter format so checkpoints interchange."""
+`step`, `zero_grad`, and `state_dict`/`load_state_dict` in the per-parameter format *and id enumeration* of the reference's
+optimizer, so optimizer checkpoints interchange with `torch.optim.AdamW(param_dicts)` built as in
+`train_cape_episodic.py:527-538`: group 0 = every trainable tensor whose name lacks "backbone" in `named_parameters`
+order -- including the 38 tensors that never receive a gradient, which hold an id but no state --
+group 1 = the backbone tensors."""
 import torch
 
 from ..hip import functional as HF
@@ -17,6 +21,15 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.arenas = [ParamGroupArena(main, device), ParamGroupArena(backbone, device)]
         self.dead = dead
         self.max_norm = max_norm
+        # reference enumeration: (group, position) -> arena slot or None (a never-trained tensor)
+        slot = {id(p): (ai, i) for ai, a in enumerate(self.arenas) for i, p in enumerate(a.params)}
+        self._layout = [[], []]
+        seen = set()
+        for n, p in model.named_parameters():
+            if not p.requires_grad or id(p) in seen:
+                continue
+            seen.add(id(p))
+            self._layout[1 if "backbone" in n else 0].append((n, tuple(p.shape), slot.get(id(p))))
         groups = [{"params": self.arenas[0].params, "lr": lr}, {"params": self.arenas[1].params, "lr": lr_backbone}]
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
@@ -49,30 +62,50 @@ class ArenaAdamW(torch.optim.Optimizer):
         """Global gradient norm of the last `step` (device tensor, no sync)."""
         return self.sumsq.sqrt()
 
-    # ---- torch-format state dicts -------------------------------------------------------------
+    # ---- torch-format state dicts, ids as the reference's optimizer assigns them ------------------------------
     def state_dict(self):
-        state, idx = {}, 0
-        groups = []
-        for a, g in zip(self.arenas, self.param_groups):
+        state, groups, idx = {}, [], 0
+        for layout, g in zip(self._layout, self.param_groups):
             ids = []
-            for p, o in zip(a.params, a.offsets):
-                state[idx] = {"step": self.step_count.clone().float().reshape(()),
-                              "exp_avg": a._view(a.exp_avg, p, o).clone(), "exp_avg_sq": a._view(a.exp_avg_sq, p, o).clone()}
+            for _, _, sl in layout:
+                if sl is not None:
+                    a = self.arenas[sl[0]]
+                    p, o = a.params[sl[1]], a.offsets[sl[1]]
+                    state[idx] = {"step": self.step_count.clone().float().reshape(()),
+                                  "exp_avg": a._view(a.exp_avg, p, o).clone(), "exp_avg_sq": a._view(a.exp_avg_sq, p, o).clone()}
                 ids.append(idx)
                 idx += 1
             groups.append({k: v for k, v in g.items() if k != "params"} | {"params": ids})
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        idx = 0
-        for a, g, sg in zip(self.arenas, self.param_groups, sd["param_groups"]):
+        """Validates the whole dict (group sizes, shapes) before the first copy: a mismatching checkpoint leaves the
+        moments untouched."""
+        sgroups = sd["param_groups"]
+        if len(sgroups) != len(self._layout):
+            raise ValueError(f"optimizer state has {len(sgroups)} param groups, expected {len(self._layout)}")
+        plan = []
+        for gi, (layout, sg) in enumerate(zip(self._layout, sgroups)):
+            if len(sg["params"]) != len(layout):
+                raise ValueError(f"param group {gi}: {len(sg['params'])} parameters in the state dict, {len(layout)} in the model "
+                                 "(the reference keeps its never-trained tensors in group 0)")
+            for pid, (name, shape, sl) in zip(sg["params"], layout):
+                st = sd["state"].get(pid)
+                if st is None:
+                    continue
+                if sl is None:
+                    raise ValueError(f"state for {name}, which never receives a gradient on the CAPE path")
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if tuple(st[k].shape) != shape:
+                        raise ValueError(f"{name}.{k}: shape {tuple(st[k].shape)} in the state dict, {shape} in the model")
+                plan.append((sl, st))
+        for g, sg in zip(self.param_groups, sgroups):
             for k, v in sg.items():
                 if k != "params":
                     g[k] = v
-            for p, o in zip(a.params, a.offsets):
-                st = sd["state"].get(idx)
-                if st is not None:
-                    a._view(a.exp_avg, p, o).copy_(st["exp_avg"])
-                    a._view(a.exp_avg_sq, p, o).copy_(st["exp_avg_sq"])
-                    self.step_count.fill_(int(float(st["step"])))
-                idx += 1
+        for sl, st in plan:
+            a = self.arenas[sl[0]]
+            p, o = a.params[sl[1]], a.offsets[sl[1]]
+            a._view(a.exp_avg, p, o).copy_(st["exp_avg"])
+            a._view(a.exp_avg_sq, p, o).copy_(st["exp_avg_sq"])
+            self.step_count.fill_(int(float(st["step"])))

@@ -56,6 +56,7 @@ class PCKEvaluator:
         self.category_correct = {}
         self.category_visible = {}
         self.image_results = []
+        self.num_images_global = None      # set by synchronize_between_processes (image_results stays process-local)
 
     def add_batch(self, pred_keypoints, gt_keypoints, bbox_widths, bbox_heights, category_ids=None, visibility=None,
                   image_ids: Optional[List] = None):
@@ -79,8 +80,9 @@ class PCKEvaluator:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
             return
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        buf = torch.zeros(2 + 2 * max_categories, dtype=torch.float64, device=dev)
+        buf = torch.zeros(3 + 2 * max_categories, dtype=torch.float64, device=dev)
         buf[0], buf[1] = self.total_correct, self.total_visible
+        buf[2 + 2 * max_categories] = len(self.image_results)
         for c in self.category_correct:
             assert 0 <= c < max_categories
             buf[2 + c] = self.category_correct[c]
@@ -88,6 +90,7 @@ class PCKEvaluator:
         dist.all_reduce(buf)
         b = buf.cpu().tolist()
         self.total_correct, self.total_visible = int(b[0]), int(b[1])
+        self.num_images_global = int(b[2 + 2 * max_categories])
         self.category_correct = {c: int(b[2 + c]) for c in range(max_categories) if b[2 + max_categories + c] > 0 or b[2 + c] > 0}
         self.category_visible = {c: int(b[2 + max_categories + c]) for c in self.category_correct}
 
@@ -97,4 +100,4 @@ class PCKEvaluator:
         return {"pck_overall": self.total_correct / self.total_visible if self.total_visible > 0 else 0.0,
                 "pck_per_category": per, "mean_pck_categories": float(np.mean(list(per.values()))) if per else 0.0,
                 "total_correct": self.total_correct, "total_visible": self.total_visible, "num_categories": len(per),
-                "num_images": len(self.image_results), "threshold": self.threshold}
+                "num_images": self.num_images_global if self.num_images_global is not None else len(self.image_results), "threshold": self.threshold}

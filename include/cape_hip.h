@@ -49,7 +49,7 @@ int cape_rng_advance(uint64_t* rng_state, cape_stream_t stream);
  * Epilogue (split_k == 1): v = acc; v = v*scale[n] (opt); v += bias[n] (opt); v += residual[m][n] (opt);
  *   relu (opt); dropout(p) (opt); gate by mask_src (opt, see the struct); then C = v or C += v (accumulate).
  * split_k > 1: partial sums are atomically added into C (C must hold the value to accumulate onto);
- *   no other epilogue op is allowed.
+ *   the only other epilogue op allowed is the bias (added once, by the first k-split).
  * Replaces: F.linear / nn.Conv2d + FrozenBatchNorm2d (+ReLU, +residual) and their autograd
  *   (models/backbone.py:32-40, torchvision Bottleneck; deformable_transformer.py:95,99-100,113,208;
  *   deformable_transformer_v2.py:314-318,323-331; roomformer_v2.py:192-201,956-968).
@@ -104,6 +104,54 @@ int cape_split_planes(const float* W, int O, int T, int C, uint16_t* hi, uint16_
  * (bias gradients: nbatch = 1; level_embed gradient: one block of a level's rows per image) */
 int cape_colsum_f32(const float* X, long long ldx, int nbatch, long long batch_stride, int M, int N, float* out,
                     int accumulate, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cached autoregressive decode step (inference): N <= 64 token rows against the decoder's weights, exact fp32 FMA.
+ *
+ * cape_decode_linear:  out = [relu]( LNin(X) [+ in_add] ) W^T [+ X2 W2^T on the first n2 columns] + bias [+ LNres(R)]
+ *   X (N, K) rows; in_gamma/in_beta != NULL: X holds a *pre-norm* sum and is layer-normalised (eps 1e-5) while it is staged
+ *   ("LayerNorm on load": the post-norm chain x' = LN(x + f(x)) of deformable_transformer_v2.py:340-365 is kept as
+ *   pre-norm sums, each consumer normalises the rows it reads); in_add (N, K) is added after the norm (`+ query_pos`);
+ *   W (Nout, K) as stored by nn.Linear; X2 (N, K2) / W2 (n2, K2): a second product for columns < n2 (n2 % 8 == 0);
+ *   R (N, Nout): residual, layer-normalised with res_gamma/res_beta when given;
+ *   the Nout columns are written as nseg (<= 3) segments of `seg` columns, segment s to out[s] with row stride ldo[s]
+ *   (q | k | v of a layer in one launch, k and v straight into row `step` of the KV cache: kv_cache.py:21-36).
+ * Replaces per layer: attn_q/k/v + MultiheadAttention in_proj (folded, deformable_transformer_v2.py:323-331), out_proj,
+ *   support_attn in/out projections, sampling_offsets|attention_weights, output_proj, linear1, linear2 and norm2 /
+ *   norm_support / norm1 / norm3 (deformable_transformer_v2.py:320-370; deformable_transformer.py:99-113).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int N, K, Nout;
+  const float* X; long long ldx; const float* in_gamma; const float* in_beta; const float* in_add; long long ld_add;
+  const float* W; long long ldw; const float* bias;
+  const float* X2; long long ldx2; int K2; const float* W2; long long ldw2; int n2;
+  const float* R; long long ldr; const float* res_gamma; const float* res_beta;
+  int relu;
+  int nseg, seg; float* out[3]; long long ldo[3];
+} cape_decode_linear_desc;
+int cape_decode_linear(const cape_decode_linear_desc* d, cape_stream_t stream);
+
+/* cape_decode_tail: what lies between two decoder layers for one token per image, one launch:
+ *   t = LN3(P4) (-> hs_out when given);  delta = MLP(t) (W1, W2: 256x256 + ReLU, W3: 2x256);
+ *   ref' = sigmoid(delta + inverse_sigmoid(ref)) (eps 1e-5 clamps, util/misc.py:436-440) -> ref_out (row stride ld_ref);
+ *   Wc != NULL (last layer): class logits Wc t + Bc -> cls_out (row stride ld_cls);
+ *   Wp != NULL (a next layer exists): qpos_out = LN(pos_trans(sine256(ref' * 2 pi)); gp, bp) and
+ *     refin_out[n][l] = ref' * valid_ratio[n][l]  (deformable_transformer_v2.py:1077-1090, :1000-1018).
+ * Replaces TransformerDecoder.forward :1083-1110 (per layer) + MLP (roomformer_v2.py:956-968) for Lq = 1. */
+typedef struct {
+  int N, L;
+  const float* P4; long long ldp; const float* g3; const float* b3;
+  const float* W1; const float* B1; const float* W2; const float* B2; const float* W3; const float* B3;
+  const float* ref;
+  const float* Wc; const float* Bc; int ncls;
+  const float* Wp; const float* Bp; const float* gp; const float* bp;
+  const float* dim_t; const float* vr;
+  float* ref_out; long long ld_ref;
+  float* qpos_out; float* refin_out;
+  float* cls_out; long long ld_cls;
+  float* hs_out; long long ld_hs;
+} cape_decode_tail_desc;
+int cape_decode_tail(const cape_decode_tail_desc* d, cape_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * out = LayerNorm(x + dropout(y)) * gamma + beta over rows of C (C <= 1024, C % 4 == 0), eps 1e-5.
@@ -204,6 +252,9 @@ int cape_attn_softmax_bwd(const float* P, float* dS, int N, int H, int Lq, int L
 /* out = a + b (n floats, n % 4 == 0 not required) */
 int cape_add_f32(const float* a, const float* b, float* out, long long n, cape_stream_t stream);
 /* out = gelu(x), exact erf form (nn.GELU default; timm Mlp act of models/bixattn.py:116-125) */
+/* out = srcs[0] + ... + srcs[k-1] (k <= 8 host-array of device pointers, n elements each): the gradient fan-in of a tensor with
+ * several consumers in one pass (what autograd's InputBuffer does with k-1 `at::add` launches). */
+int cape_add_n_f32(const float* const* srcs, int k, float* out, long long n, cape_stream_t stream);
 int cape_gelu_f32(const float* x, float* out, long long n, cape_stream_t stream);
 /* out[r][c] = x[r][c] + y[r][c] * gamma[c] (gamma may be NULL): residual behind LayerScale (models/bixattn.py:5-31,135-141) */
 int cape_scale_residual_f32(const float* x, const float* y, const float* gamma, float* out, long long rows, int C,
@@ -310,6 +361,12 @@ int cape_step_increment(int64_t* step_count, cape_stream_t stream);
  * (N,3) and coordinates (N,2) produce the next step's 4 token ids + 4 deltas and update the unfinished
  * flags; also appends logits/coords to the per-step output buffers.
  * ---------------------------------------------------------------------------------------------- */
+/* The same rules with the step index as an argument, strided logits / coordinates (a slot of the (N, T, 3) / (N, T, 2) output
+ * buffers), alive_out[0] = rows still unfinished afterwards, and -- when embed_out != NULL -- the embedding of the produced
+ * tokens for the next step (TransformerDecoder._seq_embed, deformable_transformer_v2.py:978-998; table (vocab, C)). */
+int cape_decode_advance(const float* cls_logits, long long ld_cls, const float* reg, long long ld_reg, int32_t* unfinished,
+                        int64_t* tok, float* delta, int step, int N, int num_bins, int min_len, int eos_id, int sep_id, int pad_id,
+                        const float* table, int vocab, int C, float* embed_out, int32_t* alive_out, cape_stream_t stream);
 int cape_decode_next_tokens(const float* cls_logits, const float* reg, int32_t* unfinished,
                             int64_t* tok /* (4,N): 11,12,21,22 */, float* delta /* (4,N): x1,x2,y1,y2 */,
                             const int32_t* step /* device scalar */, int N, int num_bins, int min_len,

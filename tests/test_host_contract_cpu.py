@@ -84,3 +84,98 @@ def test_pck_edge_cases():
     pred = np.array([[9.999, 0.0], [10.0, 0.0], [10.001, 0.0]], dtype=np.float64)          # bbox diagonal 50 -> 10 px at 0.2
     pck, c, v = compute_pck_bbox(pred, np.zeros((3, 2)), 30.0, 40.0, visibility=np.array([2, 1, 2]), threshold=0.2)
     assert (c, v) == (1, 3) and abs(pck - 1.0 / 3.0) < 1e-12
+
+
+def test_optimizer_state_dict_interchanges_with_reference_adamw():
+    """ArenaAdamW emits / consumes optimizer state in the id enumeration of the reference's
+    `torch.optim.AdamW(param_dicts)` (train_cape_episodic.py:527-538): never-trained tensors keep an id in group 0."""
+    import cape_amd  # noqa: F401
+    from cape_amd.runtime.optimizer import ArenaAdamW
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 6)
+            self.support_attn_layer_norms = torch.nn.ModuleList([torch.nn.LayerNorm(6)])     # never receives a gradient
+            self.backbone = torch.nn.Linear(6, 3)
+            self.b = torch.nn.Linear(3, 2)
+
+        def forward(self, x):
+            return self.b(self.backbone(torch.relu(self.a(x))))
+
+    def ref_opt(model):
+        return torch.optim.AdamW([{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad]},
+                                  {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad],
+                                   "lr": 1e-5}], lr=1e-4, weight_decay=1e-4)
+
+    torch.manual_seed(0)
+    m_ref = Toy()
+    o_ref = ref_opt(m_ref)
+    for i in range(2):
+        o_ref.zero_grad(set_to_none=True)
+        m_ref(torch.randn(5, 4)).pow(2).sum().backward()
+        o_ref.step()
+    sd_ref = o_ref.state_dict()
+    assert [len(g["params"]) for g in sd_ref["param_groups"]] == [6, 2] and 2 not in sd_ref["state"] and 3 not in sd_ref["state"]
+
+    m = Toy()
+    m.load_state_dict(m_ref.state_dict())
+    opt = ArenaAdamW(m, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    opt.load_state_dict(sd_ref)
+    assert int(opt.step_count) == 2
+    sd = opt.state_dict()
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in sd_ref["param_groups"]]
+    assert sorted(sd["state"]) == sorted(sd_ref["state"])
+    for k in sd_ref["state"]:
+        for f in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(sd["state"][k][f], sd_ref["state"][k][f]), (k, f)
+        assert float(sd["state"][k]["step"]) == float(sd_ref["state"][k]["step"])
+    assert sd["param_groups"][1]["lr"] == 1e-5
+    # and back: the reference optimizer accepts what ArenaAdamW wrote
+    o2 = ref_opt(Toy())
+    o2.load_state_dict(sd)
+    assert torch.equal(o2.state_dict()["state"][0]["exp_avg"], sd_ref["state"][0]["exp_avg"])
+    # a foreign layout is rejected before anything is copied
+    bad = {"state": dict(sd_ref["state"]), "param_groups": [dict(sd_ref["param_groups"][0], params=list(range(4))),
+                                                             dict(sd_ref["param_groups"][1], params=[4, 5])]}
+    before = opt.arenas[0].exp_avg.clone()
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
+    bad2 = {"state": {k: dict(v) for k, v in sd_ref["state"].items()}, "param_groups": sd_ref["param_groups"]}
+    bad2["state"][5]["exp_avg"] = torch.zeros(7)
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad2)
+    assert torch.equal(opt.arenas[0].exp_avg, before)
+
+
+@needs_ref
+def test_cli_parser_matches_reference_flag_by_flag():
+    """`get_args_parser()` exposes the reference's flags with the same defaults / types / choices
+    (`models/train_cape_episodic.py:86-254`); only `--dataset_root`'s author-specific default path and the added
+    `synthetic` dataset name may differ."""
+    import argparse
+    from cape_amd.models.train_cape_episodic import get_args_parser
+    refshim.install()
+    import importlib
+    ref = importlib.import_module("models.train_cape_episodic").get_args_parser()
+    ours = get_args_parser()
+
+    def table(parser):
+        out = {}
+        for a in parser._actions:
+            if isinstance(a, argparse._HelpAction):
+                continue
+            out[a.dest] = (tuple(a.option_strings), type(a).__name__, a.default, getattr(a.type, "__name__", a.type),
+                           tuple(a.choices) if a.choices else None, a.nargs)
+        return out
+
+    t_ref, t_ours = table(ref), table(ours)
+    assert set(t_ref) <= set(t_ours), f"flags missing here: {sorted(set(t_ref) - set(t_ours))}"
+    allowed_default_diff = {"dataset_root"}
+    for k, v in t_ref.items():
+        o = t_ours[k]
+        assert o[0] == v[0] and o[1] == v[1] and o[3] == v[3] and o[5] == v[5], (k, v, o)
+        if k not in allowed_default_diff:
+            assert o[2] == v[2], (k, v[2], o[2])
+        if v[4] is not None:
+            assert set(v[4]) <= set(o[4] or ()), (k, v[4], o[4])

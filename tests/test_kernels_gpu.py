@@ -815,3 +815,116 @@ def test_gemm_wgrad_fused_bias_sums(Mo, Ni, Kr, sk, prec):
         ops.set_gemm_precision(old)
     close(out, dy.t() @ x, tol=2e-4, name="tn")
     close(cs, 2.0 + dy.sum(0), tol=2e-4, name="fused bias sums")
+
+
+# ------------------------------------------------------------------------------------------------
+# fused decode step kernels (csrc/decode_step.hip, decode.hip: cape_decode_advance)
+# ------------------------------------------------------------------------------------------------
+def _ln(x, g, b):
+    return F.layer_norm(x, (x.shape[-1],), g, b, 1e-5)
+
+
+@pytest.mark.parametrize("N,K,Nout", [(1, 256, 256), (2, 256, 768), (32, 256, 384), (64, 256, 1024), (32, 1024, 256), (5, 256, 256)])
+def test_decode_linear_variants(N, K, Nout):
+    """Column-split weight-streaming product with LayerNorm-on-load of the input and of the residual, `+ pos` after the
+    norm, a second product on the first 256 columns, ReLU and three strided output segments (the q|k|v launch)."""
+    x, w, b = rnd(N, K, seed=1), rnd(Nout, K, seed=2, scale=K ** -0.5), rnd(Nout, seed=3)
+    g1, b1 = rnd(K, seed=4).abs() + 0.5, rnd(K, seed=5) * 0.1
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    # plain + relu
+    out = torch.empty(N, Nout, device=DEV)
+    ops.decode_linear(xd, wd, [out], bias=bd, relu=True)
+    close(out, F.relu(x.double() @ w.double().t() + b).float(), tol=2e-6, name="plain relu")
+    if K <= 256:
+        add = rnd(N, K, seed=6)
+        ops.decode_linear(xd, wd, [out], bias=bd, in_ln=(g1.to(DEV), b1.to(DEV)), in_add=add.to(DEV))
+        want = (_ln(x.double(), g1.double(), b1.double()) + add.double()) @ w.double().t() + b
+        close(out, want.float(), tol=5e-6, name="ln-on-load + add")
+        # broadcast rows (stride 0): the layer-0 query position embedding is one row for all images
+        row = rnd(1, K, seed=7)
+        ops.decode_linear(xd, wd, [out], in_add=row.to(DEV).expand(N, K))
+        close(out, ((x + row).double() @ w.double().t()).float(), tol=2e-6, name="broadcast add")
+    # residual with its own LayerNorm
+    r = rnd(N, Nout, seed=8)
+    g2, b2 = rnd(Nout, seed=9).abs() + 0.5, rnd(Nout, seed=10) * 0.1
+    ops.decode_linear(xd, wd, [out], bias=bd, res=r.to(DEV), res_ln=(g2.to(DEV), b2.to(DEV)))
+    close(out, (x.double() @ w.double().t() + b + _ln(r.double(), g2.double(), b2.double())).float(), tol=5e-6, name="ln residual")
+    ops.decode_linear(xd, wd, [out], res=r.to(DEV))
+    close(out, (x.double() @ w.double().t() + r).float(), tol=2e-6, name="raw residual")
+    if Nout == 768:
+        # q | k | v: second product on the first 256 columns, k / v into row 3 of a (N, 7, 256) cache
+        x2, w2 = rnd(N, 256, seed=11), rnd(256, 256, seed=12, scale=1 / 16)
+        q = torch.empty(N, 256, device=DEV)
+        kc, vc = torch.full((N, 7, 256), 9.0, device=DEV), torch.full((N, 7, 256), 9.0, device=DEV)
+        ops.decode_linear(xd, wd, [q, kc[:, 3], vc[:, 3]], bias=bd, X2=x2.to(DEV), W2=w2.to(DEV))
+        full = x.double() @ w.double().t() + b
+        full[:, :256] += x2.double() @ w2.double().t()
+        close(q, full[:, :256].float(), tol=2e-6, name="q segment")
+        close(kc[:, 3], full[:, 256:512].float(), tol=2e-6, name="k segment")
+        close(vc[:, 3], full[:, 512:].float(), tol=2e-6, name="v segment")
+        assert float((kc[:, 2] - 9).abs().sum()) == 0 and float((vc[:, 4] - 9).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("N,last", [(1, False), (32, False), (32, True), (3, True)])
+def test_decode_tail(N, last):
+    """LN3 -> coords MLP -> refinement -> (class head) -> next layer's query position embedding and level-scaled points."""
+    L = 4
+    p4 = rnd(N, 256, seed=1)
+    g3, b3 = rnd(256, seed=2).abs() + 0.5, rnd(256, seed=3) * 0.1
+    W1, B1, W2, B2 = rnd(256, 256, seed=4, scale=1 / 16), rnd(256, seed=5) * 0.1, rnd(256, 256, seed=6, scale=1 / 16), rnd(256, seed=7) * 0.1
+    W3, B3 = rnd(2, 256, seed=8, scale=1 / 16), rnd(2, seed=9) * 0.1
+    ref = torch.rand(N, 2, generator=torch.Generator().manual_seed(10))
+    ref[0] = torch.tensor([0.0, 1.0])                                   # the eps clamps of inverse_sigmoid
+    Wc, Bc = rnd(3, 256, seed=11, scale=1 / 16), rnd(3, seed=12)
+    Wp, Bp = rnd(256, 256, seed=13, scale=1 / 16), rnd(256, seed=14) * 0.1
+    gp, bp = rnd(256, seed=15).abs() + 0.5, rnd(256, seed=16) * 0.1
+    vr = torch.rand(N, L, 2, generator=torch.Generator().manual_seed(17)) * 0.5 + 0.5
+    d = lambda t_: t_.to(DEV)
+    ref_out = torch.full((N, 5, 2), 7.0, device=DEV)                    # a slot of an (N, T, 2) buffer
+    cls_out = torch.full((N, 5, 3), 7.0, device=DEV)
+    hs_out = torch.full((N, 5, 256), 7.0, device=DEV)
+    qpos, refin = torch.empty(N, 256, device=DEV), torch.empty(N, L, 2, device=DEV)
+    ops.decode_tail(d(p4), (d(g3), d(b3)), ((d(W1), d(B1)), (d(W2), d(B2)), (d(W3), d(B3))), d(ref), ref_out[:, 2], ops.dim_t(DEV),
+                    vr=d(vr), cls_head=(d(Wc), d(Bc)) if last else None, cls_out=cls_out[:, 2] if last else None,
+                    pos_trans=None if last else (d(Wp), d(Bp), d(gp), d(bp)), qpos_out=None if last else qpos,
+                    refin_out=None if last else refin, hs_out=hs_out[:, 2] if last else None)
+    t4 = _ln(p4, g3, b3)
+    delta = F.linear(F.relu(F.linear(F.relu(F.linear(t4, W1, B1)), W2, B2)), W3, B3)
+    new_ref = torch.sigmoid(delta + cape_ref.inverse_sigmoid(ref))
+    close(ref_out[:, 2], new_ref, tol=2e-6, name="refined points")
+    assert float((ref_out[:, 1] - 7).abs().sum()) == 0
+    if last:
+        close(cls_out[:, 2], F.linear(t4, Wc, Bc), tol=2e-6, name="class logits")
+        close(hs_out[:, 2], t4, tol=2e-6, name="hs")
+    else:
+        want_q = _ln(F.linear(cape_ref.query_pos_sine(new_ref[:, None])[:, 0], Wp, Bp), gp, bp)
+        close(qpos, want_q, tol=2e-5, name="next query pos")       # sin/cos of arguments up to 2 pi on the device
+        close(refin, new_ref[:, None, :] * vr, tol=2e-6, name="level-scaled points")
+
+
+def test_decode_advance_tokens_alive_and_embedding(proc_sd):
+    N = 37
+    g = torch.Generator().manual_seed(5)
+    table = proc_sd["base_model.transformer.decoder.token_embed.weight"]
+    for step in (0, 5, 6, 30):
+        logits = torch.randn(N, 4, 3, generator=g)                      # slot 1 of an (N, 4, 3) buffer
+        reg = torch.rand(N, 4, 2, generator=g) * 1.1
+        unf = torch.rand(N, generator=g) > 0.2
+        t, dl, unf2 = cape_ref.next_tokens(logits[:, 1].argmax(-1), reg[:, 1], unf.clone(), step, CFG)
+        u = unf.to(torch.int32).to(DEV)
+        tok = torch.empty(4, N, dtype=torch.int64, device=DEV)
+        de = torch.empty(4, N, device=DEV)
+        emb = torch.empty(N, 256, device=DEV)
+        alive = torch.full((3,), -1, dtype=torch.int32, device=DEV)
+        ld, rd = logits.to(DEV), reg.to(DEV)
+        ops.decode_advance(ld[:, 1], rd[:, 1], u, tok, de, step, N, 44, 6, CFG.eos, CFG.sep, CFG.pad, table=table.to(DEV),
+                           embed_out=emb, alive_out=alive[1:2])
+        for i, k in enumerate(("11", "12", "21", "22")):
+            assert torch.equal(tok[i].cpu(), t[k]), (step, k)
+        for i in range(4):
+            assert torch.equal(de[i].cpu(), dl[i]), (step, i)
+        assert torch.equal(u.cpu().bool(), unf2)
+        assert alive.cpu().tolist() == [-1, int(unf2.sum()), -1]
+        want = cape_ref.seq_embed(proc_sd, {"seq11": t["11"], "seq12": t["12"], "seq21": t["21"], "seq22": t["22"],
+                                            "delta_x1": dl[0], "delta_x2": dl[1], "delta_y1": dl[2], "delta_y2": dl[3]})
+        close(emb, want, tol=1e-6, name="next-step embedding")

@@ -202,3 +202,108 @@ def test_bixattn_blocks_match_reference(golden_dir):
     assert (ol - torch.from_numpy(d["bi0_lat"])).abs().max() <= 2e-5 and (op[:, ::5] - torch.from_numpy(d["bi0_pat"])).abs().max() <= 2e-5
     oo = cape_ref.ca_one_sided_block(lat, pat, sd_for("bixattn.one", block_spec(False, True, True)), "bixattn.one")
     assert (oo - torch.from_numpy(d["one_lat"])).abs().max() <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# round-2 fixtures (oracle/make_golden_r2.py): BASELINE configs[3] / configs[4] geometries and the training loop
+# ------------------------------------------------------------------------------------------------
+def test_cfg4_384_forward_loss_grads(golden_dir, proc_sd):
+    """configs[3] minus Swin-T: 384x384 (S = 3060 tokens), teacher-forced forward + criterion + backward."""
+    d = g(golden_dir, "cfg4_384.npz")
+    b = synth.make_batch(31, 1, 2, 384, 17, CFG, n_invisible=(2,))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in proc_sd.items()}
+    out = cape_ref.cape_forward(sd, CFG, b["images"], b["support_coords"], b["support_mask"], b["targets"],
+                                b["skeleton"], train=False, grad_mode=True)
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])[:, :, :24]
+    coords = torch.stack([a["pred_coords"] for a in out["aux_outputs"]] + [out["pred_coords"]])[:, :, :24]
+    assert (logits - t(d["logits"])).abs().max() < 1e-4
+    assert (coords - t(d["coords"])).abs().max() < 1e-5
+    losses, _, total = cape_ref.criterion(out, b["targets"], CFG)
+    for k, v in zip(json.loads(bytes(d["loss_keys"]).decode()), d["loss_vals"]):
+        assert abs(float(losses[k]) - float(v)) < 1e-4, k
+    assert abs(float(total) - float(d["loss"])) < 1e-3
+    total.backward()
+    for k in d.files:
+        if k.startswith("gradhead:"):
+            ref = t(d[k])
+            got = sd[k[9:]].grad.reshape(-1)[:256]
+            assert (got - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max())), k
+    gn = dict(zip(json.loads(bytes(d["gnorm_keys"]).decode()), d["gnorm_vals"]))
+    from oracle import procweights
+    for n in ("base_model.transformer.encoder.layers.0.self_attn.value_proj.weight", "base_model.backbone.0.body.layer2.0.conv1.weight",
+              "base_model.transformer.decoder.layers.5.linear1.weight", "support_encoder.gcn_layers.0.conv.weight"):
+        got = float(sd[procweights.canonical_key(n)].grad.norm())
+        assert abs(got - gn[n]) <= 2e-3 * gn[n], (n, got, gn[n])
+
+
+def test_cfg5_512_patch2_decode(golden_dir):
+    """configs[4]: --image_size 512 (patch-2 input_proj), P = 68, 5-shot mean-pooled support, 40 cached decode steps."""
+    from tests.helpers import cfg5_episode_batch, proc_sd_512
+    cfg = cape_ref.Cfg(patch_size=2)
+    d = g(golden_dir, "cfg5_512_decode.npz")
+    sd = proc_sd_512()
+    sd["base_model.class_embed.5.bias"] = sd["base_model.class_embed.5.bias"] + t(d["bias_delta"])
+    b = cfg5_episode_batch()
+    assert torch.equal(b["support_coords"], t(d["support_coords"])) and torch.equal(b["support_masks"], t(d["support_masks"]))
+    ref_logits, ref_coords = t(d["logits"]), t(d["coordinates"])
+    stream = cape_ref.stream_from_outputs(ref_logits, ref_coords, cfg)
+    with torch.no_grad():
+        q = cape_ref.cape_forward_inference(sd, cfg, b["query_images"], b["support_coords"], b["support_masks"],
+                                            b["support_skeletons"], max_len=40, grad_mode=False, teacher=stream)
+    assert q["logits"].shape == ref_logits.shape == (2, 40, 3)
+    assert (q["logits"] - ref_logits).abs().max() < 1e-4
+    assert (q["coordinates"] - ref_coords).abs().max() < 1e-5
+    assert torch.equal(q["sequences"], t(d["sequences"]).long())
+    assert len(set(t(d["sequences"]).reshape(-1).tolist())) >= 2          # the stream mixes token types
+
+
+def test_train_loop_parameter_deltas(golden_dir, proc_sd):
+    """`train_one_epoch_episodic` restated on the oracle (3 micro-batches, accumulation 2, clip 0.1, AdamW, tail flush;
+    reference engine_cape.py:48-301, train_cape_episodic.py:527-538), dropout 0 -- the step bench.py times as cpu_baseline."""
+    from tests.helpers import train_loop_batches
+    cfg = cape_ref.Cfg(dropout=0.0)
+    d = g(golden_dir, "train_loop.npz")
+    lr, lr_bb, wd, max_norm = (float(x) for x in d["lr"])
+    names = json.load(open(os.path.join(golden_dir, "trainable_names.json")))
+    from oracle import procweights
+    sd = {k: v.clone() for k, v in proc_sd.items()}
+    train = sorted({procweights.canonical_key(n) for n in names})
+    for n in train:
+        sd[n].requires_grad_(True)
+    for k in list(sd):                                  # alias keys share the canonical tensor
+        sd[k] = sd[procweights.canonical_key(k)]
+    before = {n: sd[n].detach().clone() for n in train}
+    opt = torch.optim.AdamW([{"params": [sd[n] for n in train if "backbone" not in n]},
+                             {"params": [sd[n] for n in train if "backbone" in n], "lr": lr_bb}], lr=lr, weight_decay=wd)
+    acc = 2
+    batches = train_loop_batches()
+
+    def flush():
+        torch.nn.utils.clip_grad_norm_([sd[n] for n in train if sd[n].grad is not None], max_norm)
+        opt.step()
+        opt.zero_grad()
+
+    for i, b in enumerate(batches):
+        out = cape_ref.cape_forward(sd, cfg, b["query_images"], b["support_coords"], b["support_masks"], b["query_targets"],
+                                    b["support_skeletons"], train=True, grad_mode=True)
+        _, _, total = cape_ref.criterion(out, b["query_targets"], cfg)
+        (total / acc).backward()
+        if (i + 1) % acc == 0:
+            flush()
+    if len(batches) % acc:
+        flush()
+    dn = dict(zip(json.loads(bytes(d["dnorm_keys"]).decode()), d["dnorm_vals"]))
+    bad = []
+    for n in train:
+        got = float((sd[n].detach() - before[n]).norm())
+        want = dn[n]
+        if abs(got - want) > 2e-2 * max(want, 1e-7):
+            bad.append((n, got, want))
+    assert not bad, bad[:5]
+    for k in d.files:
+        if k.startswith("delta:"):
+            n = procweights.canonical_key(k[6:])
+            got = (sd[n].detach() - before[n]).reshape(-1)[:512]
+            ref = t(d[k])
+            close = ((got - ref).abs() <= 5e-6).float().mean().item()      # Adam steps are ~lr * sign(g): near-zero gradients may flip
+            assert close >= 0.97, (k, close)
