@@ -692,7 +692,7 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.inv_keep = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
   p.rng_state = d->rng_state; p.rng_stream = d->rng_stream;
 
-  p.Bhi = d->B_hi; p.Blo = d->B_lo; p.ldp = d->ldp;
+  p.Bpack = d->B_packed;
   p.mask_src = d->mask_src; p.ldm = d->ldm; p.mask_scale = d->mask_scale;
   p.bdiv = d->batch_div > 0 ? d->batch_div : 1;
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
@@ -701,12 +701,9 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
                      d->dropout_p == 0.f && (d->a_mode == 0 || d->a_mode == 1) && (d->b_mode == 0 || d->b_mode == 1),
                  "cape_gemm_f32: batched launches take dense modes, no epilogue vectors, split_k 1, batch <= 65535");
   if (d->mask_src) CAPE_REQUIRE(d->split_k == 1, "cape_gemm_f32: mask_src needs split_k == 1");
-  if (d->B_hi || d->B_lo) CAPE_REQUIRE(d->B_hi && d->B_lo && d->ldp >= d->K, "cape_gemm_f32: B planes need both pointers and ldp >= K");
   CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
   // register-stationary weights (gemm_rs.hip): dense A against a <= 256-deep weight, the token products of the transformer
   if (d->precision == 1 && d->batch <= 1 && cape_gemm_rs_eligible(p, d->a_mode, d->b_mode)) return cape_gemm_rs_launch(p, d->b_mode, as_stream(stream));
-  // weight-stationary kernel when the B operand comes with pre-split planes (see gemm_ws.hip); same epilogue semantics
-  if (d->precision == 1 && d->batch <= 1 && cape_gemm_ws_eligible(p, d->a_mode)) return cape_gemm_ws_launch(p, d->a_mode, as_stream(stream));
 
   // vector path: every 16-byte load must be aligned and stay inside its row
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

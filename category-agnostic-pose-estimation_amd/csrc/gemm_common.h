@@ -45,8 +45,8 @@ struct GemmP {
   uint32_t drop_thresh; float inv_keep;
   const uint64_t* rng_state; uint32_t rng_stream;
   int tilesM, tilesN;
-  // pre-split weight planes of the B operand (bf16 bit patterns, [N][K] with leading dimension ldp), or null
-  const unsigned short* Bhi; const unsigned short* Blo; long long ldp;
+  // the B operand as fragment-ordered bf16 (hi, lo) planes (cape_pack_weights), or null: register-stationary kernel only
+  const unsigned short* Bpack;
   // optional gate of the result: v = mask_src[m][n] != 0 ? v * mask_scale : 0 (backward of a fused relu/dropout)
   const float* mask_src; long long ldm; float mask_scale;
   // batched launch (grid.y = batch): batch b = b0 * bdiv + b1 offsets the operands by b0 * s?0 + b1 * s?1 elements
@@ -60,8 +60,3 @@ constexpr int BK = 32;
 // gemm_rs.hip: register-stationary weights (dense A, K in {64, 128, 256}, bf16x3), persistent over 64-row units
 bool cape_gemm_rs_eligible(const GemmP& p, int a_mode, int b_mode);
 int cape_gemm_rs_launch(const GemmP& p, int b_mode, hipStream_t stream);
-
-// gemm_ws.hip: weight-stationary bf16x3 kernel (A straight to registers, pre-split B planes through LDS)
-bool cape_gemm_ws_eligible(const GemmP& p, int a_mode);
-int cape_gemm_ws_launch(GemmP& p, int a_mode, hipStream_t stream);
-

@@ -114,7 +114,18 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
   // ---- this wave's weight column block as B fragments: lane (r, h) holds W[k = 16 s + 8 h + j][n0 + r], j = 0..7
   bf16x8 bhi[KS], blo[KS];
   float4 ra[NV];                                   // A staging registers: a unit lives here between its load and its LDS store
-  if constexpr (BMODE == 0) {
+  if (p.Bpack) {
+    // fragment-ordered bf16 planes prepared once per optimizer step (cape_pack_weights): block (column group, k-step, plane)
+    // = 64 lanes x 16 bytes, so the whole weight block of this wave arrives as 2 * K/16 coalesced 1 KB loads -- no LDS pass,
+    // no split arithmetic, no barrier before the first MFMA
+    load_rows(ra, p.A, p.lda, slot * RS_UNIT, p.M);
+    const uint4* bp = reinterpret_cast<const uint4*>(p.Bpack) + ((long long)(n0 >> 5) * KS * 2) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bhi[s] = __builtin_bit_cast(bf16x8, bp[(2 * s + 0) * 64]);
+      blo[s] = __builtin_bit_cast(bf16x8, bp[(2 * s + 1) * 64]);
+    }
+  } else if constexpr (BMODE == 0) {
     // W stored [N][K]: the same coalesced row staging as A, 64 weight rows (two waves' columns) per pass through the two
     // LDS buffers; the owning waves then read their fragments with the conflict-free pattern of the A reads
     constexpr int NPASS = NW / 2;
@@ -286,7 +297,58 @@ int rs_launch(const GemmP& p, int nchunks, int gpc, hipStream_t s) {
   return cape_set_error("cape_gemm_f32(rs): unsupported epilogue combination");
 }
 
+// ---- weight packing: W (as the B operand of mode b_mode) -> fragment-ordered bf16 (hi, lo) planes -------------------------
+struct PackItem { const float* B; unsigned short* out; long long ldb; int N, K, b_mode, pad; };
+static_assert(sizeof(PackItem) == sizeof(cape_pack_item), "cape_pack_item layout");
+
+// one wave per (column group, k-step): lane (r, h) converts W_eff[k = 16 s + 8 h + j][n = 32 g + r], j = 0..7
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackItem* items, int n_items) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int it = blockIdx.y; it < n_items; it += gridDim.y) {
+    const PackItem q = items[it];
+    const int KS = q.K >> 4, groups = (q.N + 31) >> 5;
+    for (int w = blockIdx.x * 4 + wave; w < groups * KS; w += gridDim.x * 4) {
+      const int g = w / KS, s = w - g * KS;
+      const int n = 32 * g + r, k = 16 * s + 8 * h;
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      if (n < q.N) {
+        if (q.b_mode == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = q.B[(long long)n * q.ldb + k + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = q.B[(long long)(k + j) * q.ldb + n];
+        }
+      }
+      unsigned hw[4], lw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split2(f[2 * j], f[2 * j + 1], hw[j], lw[j]);
+      uint4* o = reinterpret_cast<uint4*>(q.out) + ((long long)w * 2) * 64 + lane;
+      o[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      o[64] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" size_t cape_packed_weight_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (size_t)((N + 31) / 32) * 32 * (size_t)K * 4;          // two bf16 planes, column groups padded to 32
+}
+
+extern "C" int cape_pack_weights(const cape_pack_item* items_dev, int n_items, int max_blocks_per_item, cape_stream_t stream) {
+  CAPE_REQUIRE(items_dev != nullptr && n_items >= 0 && max_blocks_per_item >= 1, "cape_pack_weights: bad arguments");
+  if (n_items == 0) return 0;
+  const unsigned gy = (unsigned)(n_items < 65535 ? n_items : 65535);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)max_blocks_per_item, gy), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const PackItem*>(items_dev), n_items);
+  CAPE_LAUNCH_CHECK("cape_pack_weights");
+  return 0;
+}
 
 bool cape_gemm_rs_eligible(const GemmP& p, int a_mode, int b_mode) {
   static const bool off = getenv("CAPE_GEMM_NO_RS") != nullptr;      // tuning switch: always use the tiled kernel
@@ -295,7 +357,8 @@ bool cape_gemm_rs_eligible(const GemmP& p, int a_mode, int b_mode) {
   if (p.M <= 64 || p.N < 32 || rs_epi(p) < 0) return false;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!al16(p.A) || p.lda % 4 != 0) return false;
-  if (b_mode == 0 && (!al16(p.B) || p.ldb % 4 != 0)) return false;
+  if (p.Bpack && !al16(p.Bpack)) return false;
+  if (!p.Bpack && b_mode == 0 && (!al16(p.B) || p.ldb % 4 != 0)) return false;
   const long long lim = 1ll << 31;                                   // 32-bit lane offsets in the epilogue
   if ((long long)p.M * p.ldc >= lim || (p.residual && (long long)p.M * p.ldr >= lim) || (p.mask_src && (long long)p.M * p.ldm >= lim))
     return false;

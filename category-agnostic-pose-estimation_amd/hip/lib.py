@@ -40,11 +40,15 @@ class GemmDesc(ctypes.Structure):
         ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_longlong),
         ("relu", c_int), ("accumulate", c_int), ("split_k", c_int), ("dropout_p", c_float),
         ("rng_state", c_void_p), ("rng_stream", c_uint32), ("colsum_out", c_void_p), ("precision", c_int),
-        ("B_hi", c_void_p), ("B_lo", c_void_p), ("ldp", c_longlong),
+        ("B_packed", c_void_p),
         ("mask_src", c_void_p), ("ldm", c_longlong), ("mask_scale", c_float),
         ("batch", c_int), ("batch_div", c_int), ("sA0", c_longlong), ("sA1", c_longlong), ("sB0", c_longlong), ("sB1", c_longlong),
         ("sC0", c_longlong), ("sC1", c_longlong),
     ]
+
+
+class PackItem(ctypes.Structure):
+    _fields_ = [("B", c_void_p), ("out", c_void_p), ("ldb", c_longlong), ("N", c_int), ("K", c_int), ("b_mode", c_int), ("pad", c_int)]
 
 
 class DecodeLinearDesc(ctypes.Structure):
@@ -78,7 +82,7 @@ P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
 _SIGS = {
     "cape_rng_advance": [P, P],
     "cape_gemm_f32": [POINTER(GemmDesc), P],
-    "cape_split_planes": [P, I, I, I, P, P, P, P, P],
+    "cape_pack_weights": [P, I, I, P],
     "cape_colsum_f32": [P, LL, I, LL, I, I, P, I, P],
     "cape_add_layernorm_fwd": [P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
     "cape_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],
@@ -126,7 +130,9 @@ _SIGS = {
     "cape_decode_linear": [POINTER(DecodeLinearDesc), P],
     "cape_decode_tail": [POINTER(DecodeTailDesc), P],
 }
-EXPORTS = ["cape_last_error", "cape_abi_version", "cape_groupnorm_workspace_bytes"] + list(_SIGS)
+EXPORTS = ["cape_last_error", "cape_abi_version", "cape_groupnorm_workspace_bytes", "cape_packed_weight_bytes"] + list(_SIGS)
+_lib.cape_packed_weight_bytes.argtypes = [I, I]
+_lib.cape_packed_weight_bytes.restype = c_size_t
 _lib.cape_groupnorm_workspace_bytes.argtypes = [I, I, I]
 _lib.cape_groupnorm_workspace_bytes.restype = c_size_t
 

@@ -7,6 +7,7 @@ whole GPU node down), and raises if the library reports an error.  No CPU path e
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 
@@ -125,24 +126,98 @@ def get_gemm_precision():
     return {0: "f32", 1: "bf16x3"}[GEMM_PRECISION]
 
 
-def split_planes(W, O, T, C, want_plain=True, want_transposed=True):
-    """bf16 (hi, lo) planes of a weight W viewed as (O, T, C): plain [O][T*C] and/or transposed [C][T*O] (int16 tensors).
-    Returns (hi, lo, hiT, loT) with None for the pair not asked for."""
-    _chk(W, "split_planes.W")
-    assert W.numel() == O * T * C
-    mk = lambda r, c: torch.empty(r, c, dtype=torch.int16, device=W.device)
-    hi = mk(O, T * C) if want_plain else None
-    lo = mk(O, T * C) if want_plain else None
-    hiT = mk(C, T * O) if want_transposed else None
-    loT = mk(C, T * O) if want_transposed else None
-    lib.call("cape_split_planes", _p(W), O, T, C, _p(hi), _p(lo), _p(hiT), _p(loT), _stream())
-    return hi, lo, hiT, loT
+class PackedWeights:
+    """Registry of fragment-packed weights for the register-stationary GEMM (csrc/gemm_rs.hip, cape_pack_weights).
+
+    A weight that multiplies token rows as the B operand of a dense product with K in {64, 128, 256} is kept, next to its fp32
+    master copy, as bf16 (hi, lo) planes in the lane order of the MFMA B fragment: the kernel's per-block weight prologue is
+    then K/8 coalesced loads per wave.  Entries are keyed by (storage address, N, K, ldb, b_mode) -- the forward use and the
+    dgrad use of one nn.Linear are two entries -- and are valid for one (epoch, tensor version):
+      * `invalidate_and_repack()` (called by ArenaAdamW.step(), whose kernel updates the flat arena behind autograd's back)
+        re-packs every registered entry with ONE launch over a device-resident item table;
+      * any other in-place change (load_state_dict, manual edits) bumps the parameter's `_version`: that entry is re-packed
+        alone at its next use.
+    Only tensors that are (views of) nn.Parameters are packed: the B operand of every dense a_mode-0 product of the model."""
+    enabled = os.environ.get("CAPE_GEMM_PACKED", "1") == "1"
+    epoch = 0
+    entries = {}
+    _table = None            # (device tensor of cape_pack_item, n) rebuilt when entries are added
+
+    @classmethod
+    def lookup(cls, B, N, K, ldb, b_mode):
+        base = B if isinstance(B, torch.nn.Parameter) else B._base
+        if not isinstance(base, torch.nn.Parameter):
+            return None
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (B.data_ptr(), N, K, int(ldb), b_mode)
+        e = cls.entries.get(key)
+        if e is not None and e["base"]() is not base:          # the parameter that owned this address is gone: start over
+            e = None
+        if e is None:
+            if capturing:
+                return None                                    # never allocate / register inside a graph capture
+            nbytes = lib.raw().cape_packed_weight_bytes(N, K)
+            e = {"buf": torch.empty(nbytes // 2, dtype=torch.int16, device=B.device), "epoch": -1, "version": -1,
+                 "base": weakref.ref(base), "item": (B.data_ptr(), N, K, int(ldb), b_mode)}
+            cls.entries[key] = e
+            cls._table = None
+        if e["epoch"] != cls.epoch or e["version"] != base._version:
+            if capturing:
+                return None                                    # stale inside a capture: the kernel splits the fp32 weight itself
+            cls._pack([e])
+            e["epoch"], e["version"] = cls.epoch, base._version
+        return e["buf"]
+
+    @classmethod
+    def _items(cls, es):
+        arr = (lib.PackItem * len(es))()
+        for i, e in enumerate(es):
+            ptr, N, K, ldb, mode = e["item"]
+            arr[i].B, arr[i].out, arr[i].ldb, arr[i].N, arr[i].K, arr[i].b_mode = ptr, e["buf"].data_ptr(), ldb, N, K, mode
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        return host
+
+    @classmethod
+    def _pack(cls, es):
+        dev = es[0]["buf"].device
+        tab = cls._items(es).to(dev)
+        lib.call("cape_pack_weights", _p(tab), len(es), 16, _stream())
+        es[0].setdefault("_keep", None)
+        es[0]["_keep"] = tab                                    # the table must outlive the asynchronous launch
+
+    @classmethod
+    def invalidate_and_repack(cls):
+        """All registered weights changed (optimizer step): one launch re-packs them; entries become valid for the new epoch."""
+        cls.epoch += 1
+        if not cls.enabled or not cls.entries:
+            return
+        dead = [k for k, e in cls.entries.items() if e["base"]() is None]
+        if dead and not torch.cuda.is_current_stream_capturing():
+            for k in dead:
+                del cls.entries[k]
+            cls._table = None
+        es = list(cls.entries.values())
+        if not es:
+            return
+        if cls._table is None or cls._table[1] != len(es):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PackedWeights: new weights were registered inside a graph capture")
+            cls._table = (cls._items(es).to(es[0]["buf"].device), len(es))
+        lib.call("cape_pack_weights", _p(cls._table[0]), len(es), 16, _stream())
+        for e in es:
+            b = e["base"]()
+            e["epoch"], e["version"] = cls.epoch, (b._version if b is not None else -1)
+
+    @classmethod
+    def clear(cls):
+        cls.entries, cls._table = {}, None
 
 
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None,
-         colsum_out=None, planes=None, mask_src=None, mask_scale=1.0, batch=None):
-    """planes = (hi, lo, ldp): the B operand pre-split into bf16 planes [N][K] (split_planes); optional."""
+         colsum_out=None, packed=None, mask_src=None, mask_scale=1.0, batch=None):
+    """packed: the B operand as fragment-ordered bf16 planes (PackedWeights / cape_pack_weights); looked up automatically when B
+    is a parameter (or a view of one) and the product is one the register-stationary kernel takes."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
         _chk(t, "gemm." + n, contiguous=False)
     d = lib.GemmDesc()
@@ -162,11 +237,12 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.rng_state = rng.t.data_ptr() if (rng is not None and dropout_p > 0) else None
     d.rng_stream = rng_stream
     d.precision = GEMM_PRECISION
-    if planes is not None and GEMM_PRECISION == 1:
-        ph, pl, ldp = planes
-        assert ph.dtype == torch.int16 and pl.dtype == torch.int16 and ph.is_cuda and pl.is_cuda
-        assert N == 0 or (_avail(ph) >= (N - 1) * ldp + K and _avail(pl) >= (N - 1) * ldp + K), "gemm: planes too small"
-        d.B_hi, d.B_lo, d.ldp = ph.data_ptr(), pl.data_ptr(), ldp
+    if (packed is None and PackedWeights.enabled and GEMM_PRECISION == 1 and a_mode == 0 and b_mode in (0, 1) and batch is None
+            and split_k == 1 and K in (64, 128, 256) and M > 64 and N >= 32):
+        packed = PackedWeights.lookup(B, N, K, d.ldb, b_mode)
+    if packed is not None and GEMM_PRECISION == 1:
+        assert packed.dtype == torch.int16 and packed.is_cuda and packed.numel() * 2 >= lib.raw().cape_packed_weight_bytes(N, K)
+        d.B_packed = packed.data_ptr()
     if mask_src is not None:
         _chk(mask_src, "gemm.mask_src")
         assert mask_src.numel() == M * N and split_k == 1

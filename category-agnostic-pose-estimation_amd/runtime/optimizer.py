@@ -51,6 +51,9 @@ class ArenaAdamW(torch.optim.Optimizer):
                 b1, b2 = g["betas"]
                 ops.adamw_step(a.data, a.grad, a.exp_avg, a.exp_avg_sq, g["lr"], b1, b2, g["eps"], g["weight_decay"],
                                self.max_norm, self.sumsq, self.step_count)
+        # the kernel above rewrote every weight behind autograd's version counters: re-pack the MFMA-fragment copies the
+        # register-stationary GEMM reads (one launch over the registered table)
+        ops.PackedWeights.invalidate_and_repack()
 
     def zero_grad(self, set_to_none=False):
         for a in self.arenas:

@@ -77,11 +77,11 @@ typedef struct {
                               k-split; the caller provides the value to accumulate onto) */
   int precision;           /* 0 = exact fp32 MFMA; 1 = bf16x3 split (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32
                               accumulate, ~2^-16 relative per product); odd/unaligned shapes always use 0 */
-  /* optional (precision 1; a_mode 0, 2, 3): the B operand pre-split into bf16 planes laid out [N][K] with leading
-     dimension ldp (cape_split_planes: the as-stored planes of a weight for forward products, the transposed planes
-     for dgrad).  When given and the shape qualifies (K % 32 == 0, aligned rows, conv channels % 16 == 0) the
-     weight-stationary kernel runs; otherwise B / b_mode are used as before.  Must describe the same matrix as B. */
-  const uint16_t* B_hi; const uint16_t* B_lo; long long ldp;
+  /* optional (precision 1): the B operand as fragment-ordered bf16 (hi, lo) planes written by cape_pack_weights for this
+     (N, K, ldb, b_mode).  Only the register-stationary kernel (dense A, K in {64, 128, 256}) reads it: its per-block weight
+     prologue becomes K/8 coalesced loads per wave instead of a load -> split -> LDS -> fragment pass; every other shape
+     ignores the field.  Must describe the same matrix as B / b_mode (B itself stays required). */
+  const uint16_t* B_packed;
   /* optional gate applied last (split_k == 1): v = mask_src[m][n] != 0 ? v * mask_scale : 0, mask_src (M, ldm).  With
      mask_src = the saved output of a fused linear+ReLU(+dropout p) and mask_scale = 1/(1-p), the dgrad of the *next*
      layer emits the pre-activation gradient directly (FFN backward without a separate relu/dropout-backward pass). */
@@ -94,11 +94,12 @@ typedef struct {
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
 
-/* Split a weight W (O, T, C) fp32 (nn.Linear: T = 1; channels_last conv weight: T = KH*KW) into bf16 planes
- * x = hi + lo:  hi/lo [O][T*C] (as stored) and/or hiT/loT [C][T*O] (operand of the transposed product).  Either pair may
- * be NULL.  Run once per optimizer step per weight; feeds cape_gemm_desc.B_hi/B_lo. */
-int cape_split_planes(const float* W, int O, int T, int C, uint16_t* hi, uint16_t* lo, uint16_t* hiT, uint16_t* loT,
-                      cape_stream_t stream);
+/* Weight packing for cape_gemm_desc.B_packed.  An item describes one weight as a B operand (b_mode 0: stored [N][K], nn.Linear
+ * forward; b_mode 1: stored [K][N], its dgrad) and the destination of cape_packed_weight_bytes(N, K) bytes.  `items_dev` is a
+ * DEVICE array, so the table of all weights of a model is uploaded once and one launch per optimizer step re-packs them. */
+typedef struct { const float* B; uint16_t* out; long long ldb; int N, K, b_mode, pad; } cape_pack_item;
+size_t cape_packed_weight_bytes(int N, int K);
+int cape_pack_weights(const cape_pack_item* items_dev, int n_items, int max_blocks_per_item, cape_stream_t stream);
 
 /* column sums over nbatch row blocks:  out[n] (+)= sum_b sum_m X[b*batch_stride + m*ldx + n]
  * (bias gradients: nbatch = 1; level_embed gradient: one block of a level's rows per image) */

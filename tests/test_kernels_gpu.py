@@ -173,74 +173,51 @@ def test_conv_fwd_dgrad_wgrad(N, H, W, C, O, k, stride, pad):
     close(dw.view(O, k, k, C).permute(0, 3, 1, 2), w.grad, tol=2e-4, name="conv wgrad")
 
 
-# ---- weight-stationary path (pre-split bf16 planes of the weight operand) ----
-def test_split_planes_reconstruct_and_transpose():
-    O, T, C = 70, 9, 48
-    w = rnd(O, T, C, seed=21)
-    hi, lo, hiT, loT = ops.split_planes(w.to(DEV), O, T, C)
-    f = lambda t: t.view(torch.bfloat16).float().cpu()
-    rec = f(hi) + f(lo)
-    assert (rec.view(O, T, C) - w).abs().max().item() <= 2.0 ** -16 * w.abs().max().item()
-    assert torch.equal(f(hi).view(O, T, C), w.to(torch.bfloat16).float())                     # hi = RNE bf16(x)
-    assert torch.equal(f(hiT).view(C, T, O), f(hi).view(O, T, C).permute(2, 1, 0))
-    assert torch.equal(f(loT).view(C, T, O), f(lo).view(O, T, C).permute(2, 1, 0))
-
-
-@pytest.mark.parametrize("M,N,K", [(300, 70, 256), (1000, 256, 1024), (5000, 1024, 256), (17, 256, 64), (40000, 256, 256)])
-def test_gemm_ws_linear_fwd_and_dgrad(M, N, K):
+# ---- fragment-packed weights of the register-stationary kernel (cape_pack_weights, ops.PackedWeights) ----
+@pytest.mark.parametrize("M,N,K,bm", [(5000, 256, 256, 0), (700, 384, 256, 1), (6400, 1024, 256, 0), (333, 100, 128, 1), (4097, 64, 64, 0)])
+def test_gemm_rs_packed_weights(M, N, K, bm):
+    """A parameter used as the B operand is packed once into MFMA-fragment order; the packed launch must reproduce the launch
+    that splits the fp32 weight itself bit for bit (same bf16 planes, same MFMA order), for row slices of a parameter too
+    (MultiheadAttention.in_proj), and follow in-place updates of the weight."""
     if ops.get_gemm_precision() != "bf16x3":
-        pytest.skip("the weight-stationary kernel is the bf16x3 path")
-    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
-    res = rnd(M, N, seed=4)
-    xd, wd = x.to(DEV), w.to(DEV)
-    hi, lo, hiT, loT = ops.split_planes(wd, N, 1, K)
-    out = torch.empty(M, N, device=DEV)
-    ops.gemm(xd, wd, out, M, N, K, bias=b.to(DEV), residual=res.to(DEV), relu=True, planes=(hi, lo, K))
-    close(out, F.relu(F.linear(x, w, b) + res), name="ws fwd")
-    # against the general bf16x3 kernel: same arithmetic up to summation order
-    out2 = torch.empty(M, N, device=DEV)
-    ops.gemm(xd, wd, out2, M, N, K, bias=b.to(DEV), residual=res.to(DEV), relu=True)
-    close(out, out2.cpu(), tol=2e-5, name="ws vs general")
-    # dgrad: dx[M,K] = dy[M,N] @ W[N,K]  -> planes of W^T ([K][N])
-    dy = rnd(M, N, seed=6)
-    dx = torch.empty(M, K, device=DEV)
-    ops.gemm(dy.to(DEV), wd, dx, M, K, N, a_mode=0, b_mode=1, planes=(hiT, loT, N))
-    close(dx, dy @ w, name="ws dgrad")
-    # a row slice of the weight (MHA in_proj): rows [N//2:], and the matching column slice of the transposed planes
-    if N % 2 == 0 and (N // 2) % 8 == 0:
+        pytest.skip("packed weights feed the bf16x3 register-stationary kernel")
+    ops.PackedWeights.clear()
+    x = rnd(M, K, seed=1).to(DEV)
+    w = torch.nn.Parameter((rnd(N, K, seed=2, scale=K ** -0.5) if bm == 0 else rnd(K, N, seed=2, scale=K ** -0.5)).to(DEV))
+    b = rnd(N, seed=3).to(DEV)
+    plain, packed = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.PackedWeights.enabled = False
+    ops.gemm(x, w.detach(), plain, M, N, K, b_mode=bm, bias=b, relu=True)
+    ops.PackedWeights.enabled = True
+    ops.gemm(x, w, packed, M, N, K, b_mode=bm, bias=b, relu=True)
+    assert len(ops.PackedWeights.entries) == 1
+    assert torch.equal(plain, packed)
+    # in-place edit -> version bump -> re-packed at the next use
+    with torch.no_grad():
+        w.mul_(0.5)
+    ops.gemm(x, w, packed, M, N, K, b_mode=bm, bias=b, relu=True)
+    ops.PackedWeights.enabled = False
+    ops.gemm(x, w.detach(), plain, M, N, K, b_mode=bm, bias=b, relu=True)
+    ops.PackedWeights.enabled = True
+    assert torch.equal(plain, packed)
+    # raw update behind autograd's back (what the fused AdamW kernel does) + the batched re-pack
+    w.data.view(-1)[::3].add_(0.25)                   # .data: no version bump
+    stale = torch.empty(M, N, device=DEV)
+    ops.gemm(x, w, stale, M, N, K, b_mode=bm, bias=b, relu=True)
+    ops.PackedWeights.invalidate_and_repack()
+    ops.gemm(x, w, packed, M, N, K, b_mode=bm, bias=b, relu=True)
+    ops.PackedWeights.enabled = False
+    ops.gemm(x, w.detach(), plain, M, N, K, b_mode=bm, bias=b, relu=True)
+    ops.PackedWeights.enabled = True
+    assert torch.equal(plain, packed) and not torch.equal(stale, packed)
+    if bm == 0 and N % 64 == 0:                       # a row slice of the parameter (its own entry)
         h = N // 2
-        o3 = torch.empty(M, h, device=DEV)
-        ops.gemm(xd, wd[h:], o3, M, h, K, planes=(hi[h:], lo[h:], K))
-        close(o3, x @ w[h:].t(), name="ws fwd row slice")
-        d3 = torch.empty(M, K, device=DEV)
-        ops.gemm(dy[:, h:].contiguous().to(DEV), wd[h:], d3, M, K, h, a_mode=0, b_mode=1, planes=(hiT[:, h:], loT[:, h:], N))
-        close(d3, dy[:, h:] @ w[h:], name="ws dgrad row slice")
-
-
-@pytest.mark.parametrize("N,H,W,C,O,k,stride,pad", [(2, 16, 16, 64, 64, 3, 1, 1), (2, 17, 15, 32, 48, 3, 2, 1),
-                                                    (3, 16, 16, 64, 128, 1, 2, 0), (1, 8, 8, 256, 256, 3, 2, 1),
-                                                    (4, 32, 32, 128, 128, 3, 1, 1)])
-def test_gemm_ws_conv_fwd_and_dgrad(N, H, W, C, O, k, stride, pad):
-    if ops.get_gemm_precision() != "bf16x3":
-        pytest.skip("the weight-stationary kernel is the bf16x3 path")
-    x, w, geom, OH, OW = _conv_case(N, H, W, C, O, k, stride, pad)
-    sc, sh = rnd(O, seed=7).abs() + 0.5, rnd(O, seed=8)
-    x.requires_grad_(True)
-    y_ref = F.conv2d(x, w, stride=stride, padding=pad)
-    z_ref = F.relu(y_ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    g = rnd(*y_ref.shape, seed=9)
-    y_ref.backward(g)
-    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
-    wn = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)                 # (O,KH,KW,C)
-    hi, lo, hiT, loT = ops.split_planes(wn, O, k * k, C)
-    M, K = N * OH * OW, k * k * C
-    out = torch.empty(M, O, device=DEV)
-    ops.gemm(xn, wn, out, M, O, K, a_mode=2, b_mode=0, conv=geom, scale=sc.to(DEV), bias=sh.to(DEV), relu=True, planes=(hi, lo, K))
-    close(out.view(N, OH, OW, O).permute(0, 3, 1, 2), z_ref, name="ws conv fwd")
-    gn = g.permute(0, 2, 3, 1).contiguous().to(DEV)
-    dx = torch.empty(N * H * W, C, device=DEV)
-    ops.gemm(gn, wn, dx, N * H * W, C, k * k * O, a_mode=3, b_mode=2, conv=geom, planes=(hiT, loT, k * k * O))
-    close(dx.view(N, H, W, C).permute(0, 3, 1, 2), x.grad, tol=2e-4, name="ws conv dgrad")
+        ops.gemm(x, w[h:], packed[:, :h], M, h, K, ldc=N)
+        ops.PackedWeights.enabled = False
+        ops.gemm(x, w.detach()[h:], plain[:, :h], M, h, K, ldc=N)
+        ops.PackedWeights.enabled = True
+        assert torch.equal(plain[:, :h], packed[:, :h]) and len(ops.PackedWeights.entries) == 2
+    ops.PackedWeights.clear()
 
 
 def test_gemm_mask_epilogue_and_ffn_autograd():
