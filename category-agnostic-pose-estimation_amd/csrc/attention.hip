@@ -168,8 +168,16 @@ __global__ void __launch_bounds__(64) attn_decode_kernel(const float* __restrict
   __syncthreads();                                 // one wave: orders the LDS writes above before the reads below
   const int c = lane & 31, half = lane >> 5;
   const float* vb = V + (long long)n * p.bsv + h * HD + c;
-  float acc = 0.f;
-  for (int j = half; j < jmax; j += 2) acc += sc[j] * vb[(long long)j * p.ldv];
+  // four independent partial sums: the V rows of four keys are in flight together (a single chain serialises the loads)
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int j = half;
+  for (; j + 6 < jmax; j += 8) {
+    const float v0 = vb[(long long)j * p.ldv], v1 = vb[(long long)(j + 2) * p.ldv];
+    const float v2 = vb[(long long)(j + 4) * p.ldv], v3 = vb[(long long)(j + 6) * p.ldv];
+    acc0 = fmaf(sc[j], v0, acc0); acc1 = fmaf(sc[j + 2], v1, acc1); acc2 = fmaf(sc[j + 4], v2, acc2); acc3 = fmaf(sc[j + 6], v3, acc3);
+  }
+  for (; j < jmax; j += 2) acc0 = fmaf(sc[j], vb[(long long)j * p.ldv], acc0);
+  float acc = (acc0 + acc1) + (acc2 + acc3);
   acc += __shfl_xor(acc, 32, 64);
   if (lane < 32) O[(long long)n * p.bso + h * HD + c] = acc / l;
   if (lane == 0) lse[(long long)n * p.H + h] = m + __logf(l);

@@ -40,98 +40,97 @@ struct DecLinP {
   int nseg, seg; float* out[3]; long long ldo[3];
 };
 
-// mean / rstd of N rows of width C (C <= 1024, C % 4 == 0): wave w takes rows w, w+8, ...
-__device__ __forceinline__ void row_stats(const float* src, long long ld, int N, int C, float* mean_s, float* rstd_s) {
+// LayerNorm of rows held in LDS, in place: wave w takes rows w, w+8, ... (C <= 1024 handled in chunks of 256 by the callers
+// that need it: here C == row length in LDS == 256)
+__device__ __forceinline__ void ln_rows_lds(float* rows, int ld, int N, const float* gamma, const float* beta, const float* add,
+                                            long long ld_add) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = wave; r < N; r += 8) {
-    const float* p = src + (long long)r * ld;
-    float s = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(p + c);
-      s += v.x + v.y + v.z + v.w;
+    float4 v = *reinterpret_cast<float4*>(&rows[r * ld + 4 * lane]);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) / 256.f;
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) / 256.f + 1e-5f);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+    const float4 be = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    v = make_float4(a * rstd * g.x + be.x, b * rstd * g.y + be.y, c * rstd * g.z + be.z, d * rstd * g.w + be.w);
+    if (add) {
+      const float4 q = *reinterpret_cast<const float4*>(add + (long long)r * ld_add + 4 * lane);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(p + c);
-      const float a = v.x - mean, b = v.y - mean, d = v.z - mean, e = v.w - mean;
-      q += a * a + b * b + d * d + e * e;
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
-    if (lane == 0) { mean_s[r] = mean; rstd_s[r] = rstd; }
+    *reinterpret_cast<float4*>(&rows[r * ld + 4 * lane]) = v;
   }
 }
 
+// LDS: xs[N][260] | ws[8][260] | rs[N][260] (normalised residual rows, only with res_gamma).
+// Every global operand of the first k-chunk is requested before the first wait: the kernel's critical path is ONE memory
+// round trip (+ one per extra k-chunk / second product), then LDS-resident LayerNorms, then the dot products.
 __global__ void __launch_bounds__(512) decode_linear_kernel(const DecLinP p) {
-  extern __shared__ __attribute__((aligned(16))) float dl_lds[];              // xs[N][260] | ws[8][260] | 4 x stats[N]
+  extern __shared__ __attribute__((aligned(16))) float dl_lds[];
+  constexpr int LD = DL_KC + 4;
   float* xs = dl_lds;
-  float* ws = xs + p.N * (DL_KC + 4);
-  float* mean_i = ws + DL_COLS * (DL_KC + 4);
-  float* rstd_i = mean_i + p.N;
-  float* mean_r = rstd_i + p.N;
-  float* rstd_r = mean_r + p.N;
+  float* ws = xs + p.N * LD;
+  float* rs = ws + DL_COLS * LD;
   const int t = threadIdx.x;
   const int n0 = blockIdx.x * DL_COLS;
   const int col = t & (DL_COLS - 1), row = t >> 3;
-  constexpr int LD = DL_KC + 4;
-  if (p.in_gamma) row_stats(p.X, p.ldx, p.N, p.K, mean_i, rstd_i);
-  if (p.res_gamma) row_stats(p.R, p.ldr, p.N, p.Nout, mean_r, rstd_r);
-  if (p.in_gamma || p.res_gamma) __syncthreads();
   float acc = 0.f;
-  // products: pass 0 = X W^T over K, pass 1 = X2 W2^T over K2 (only for blocks whose columns lie below n2)
   const int npass = (p.X2 && n0 < p.n2) ? 2 : 1;
+  bool res_staged = false;
   for (int pass = 0; pass < npass; ++pass) {
     const float* X = pass ? p.X2 : p.X;
     const long long ldx = pass ? p.ldx2 : p.ldx;
     const float* W = pass ? p.W2 : p.W;
     const long long ldw = pass ? p.ldw2 : p.ldw;
     const int K = pass ? p.K2 : p.K;
-    const bool ln = !pass && p.in_gamma;
+    const bool ln = !pass && p.in_gamma;                       // host-checked: LN-on-load only with K == 256
     for (int k0 = 0; k0 < K; k0 += DL_KC) {
       const int kc = min(DL_KC, K - k0), kq = kc >> 2;
       if (pass || k0) __syncthreads();
+      for (int i = t; i < DL_COLS * kq; i += 512) {            // weights first: they are the bytes that come from far away
+        const int r = i / kq, c = (i - r * kq) * 4;
+        const int n = min(n0 + r, p.Nout - 1);
+        *reinterpret_cast<float4*>(&ws[r * LD + c]) = *reinterpret_cast<const float4*>(W + (long long)n * ldw + k0 + c);
+      }
       for (int i = t; i < p.N * kq; i += 512) {
         const int r = i / kq, c = (i - r * kq) * 4;
         float4 v = *reinterpret_cast<const float4*>(X + (long long)r * ldx + k0 + c);
-        if (ln) {
-          const float4 g = *reinterpret_cast<const float4*>(p.in_gamma + k0 + c);
-          const float4 b = *reinterpret_cast<const float4*>(p.in_beta + k0 + c);
-          const float m = mean_i[r], s = rstd_i[r];
-          v.x = (v.x - m) * s * g.x + b.x; v.y = (v.y - m) * s * g.y + b.y;
-          v.z = (v.z - m) * s * g.z + b.z; v.w = (v.w - m) * s * g.w + b.w;
-        }
-        if (!pass && p.in_add) {
+        if (!ln && !pass && p.in_add) {
           const float4 a = *reinterpret_cast<const float4*>(p.in_add + (long long)r * p.ld_add + k0 + c);
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
         *reinterpret_cast<float4*>(&xs[r * LD + c]) = v;
       }
-      for (int i = t; i < DL_COLS * kq; i += 512) {
-        const int r = i / kq, c = (i - r * kq) * 4;
-        const int n = min(n0 + r, p.Nout - 1);
-        *reinterpret_cast<float4*>(&ws[r * LD + c]) = *reinterpret_cast<const float4*>(W + (long long)n * ldw + k0 + c);
+      if (!res_staged && p.res_gamma) {                        // residual rows (width Nout == 256, host-checked) for their LayerNorm
+        for (int i = t; i < p.N * 64; i += 512) {
+          const int r = i >> 6, c = (i & 63) * 4;
+          *reinterpret_cast<float4*>(&rs[r * LD + c]) = *reinterpret_cast<const float4*>(p.R + (long long)r * p.ldr + c);
+        }
       }
       __syncthreads();
+      if (ln || (!res_staged && p.res_gamma)) {
+        if (ln) ln_rows_lds(xs, LD, p.N, p.in_gamma, p.in_beta, p.in_add, p.ld_add);
+        if (!res_staged && p.res_gamma) ln_rows_lds(rs, LD, p.N, p.res_gamma, p.res_beta, nullptr, 0);
+        res_staged = true;
+        __syncthreads();
+      }
       if (row < p.N) {
         const float* xr = &xs[row * LD];
         const float* wr = &ws[col * LD];
-#pragma unroll 4
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
         for (int k = 0; k < kc; k += 4) {
           const float4 a = *reinterpret_cast<const float4*>(xr + k);
           const float4 b = *reinterpret_cast<const float4*>(wr + k);
-          acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+          a0 = fmaf(a.x, b.x, a0); a1 = fmaf(a.y, b.y, a1); a2 = fmaf(a.z, b.z, a2); a3 = fmaf(a.w, b.w, a3);
         }
+        acc += (a0 + a1) + (a2 + a3);
       }
     }
   }
   const int n = n0 + col;
   if (row < p.N && n < p.Nout) {
     float v = acc + (p.bias ? p.bias[n] : 0.f);
-    if (p.R) {
-      float r = p.R[(long long)row * p.ldr + n];
-      if (p.res_gamma) r = (r - mean_r[row]) * rstd_r[row] * p.res_gamma[n] + p.res_beta[n];
-      v += r;
-    }
+    if (p.R) v += p.res_gamma ? rs[row * LD + n] : p.R[(long long)row * p.ldr + n];
     if (p.relu) v = fmaxf(v, 0.f);
     const int sg = n / p.seg;
     p.out[sg][(long long)row * p.ldo[sg] + (n - sg * p.seg)] = v;
@@ -161,23 +160,60 @@ __device__ __forceinline__ float inv_sigmoid_f(float x) {
   return logf(x1 / x2);
 }
 
-// y[j] = act(b[j] + W[j][:] . x) for j = wave, wave + 8, ... < nout; x lives in registers (4 consecutive k per lane)
-__device__ __forceinline__ void wave_gemv(const float* W, const float* B, const float4 x, float* y, int nout, bool relu) {
+// ---- tail building blocks.  A wave owns outputs j = wave + 8 i, i = 0..31 of a 256 x 256 product; x lives in registers
+// (4 consecutive k per lane), so does the wave's 32 x 1 KB weight block (128 VGPRs): all of it is requested at once.
+struct WRows { float4 w[32]; };
+
+__device__ __forceinline__ void load_rows256(WRows& r, const float* W) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < nout; j += 8) {
-    const float4 w = *reinterpret_cast<const float4*>(W + (long long)j * 256 + 4 * lane);
-    float s = fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, w.w * x.w)));
-    s = wave_sum(s);
-    if (lane == 0) { s += B ? B[j] : 0.f; y[j] = relu ? fmaxf(s, 0.f) : s; }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) r.w[i] = *reinterpret_cast<const float4*>(W + (long long)(wave + 8 * i) * 256 + 4 * lane);
+}
+
+// 32 dot products per wave reduced over the 64 lanes with 32 shuffles instead of 32 x 6: each round a lane keeps half of its
+// values (which half = one bit of the lane id) and hands the other half to the partner that keeps them, so after the rounds
+// 32..2 every lane holds ONE output summed over its 32-lane class and a last exchange with lane ^ 1 finishes it.
+// The output a lane ends up with is i = bits (5 4 3 2 1) of the lane id read as (b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1).
+__device__ __forceinline__ void gemv256(const WRows& r, const float* B, const float4 x, float* y, bool relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s[i] = fmaf(r.w[i].x, x.x, fmaf(r.w[i].y, x.y, fmaf(r.w[i].z, x.z, r.w[i].w * x.w)));
+#pragma unroll
+  for (int n = 16, o = 32; n >= 1; n >>= 1, o >>= 1) {
+    const bool up = lane & o;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float keep = up ? s[2 * i + 1] : s[2 * i], send = up ? s[2 * i] : s[2 * i + 1];
+      s[i] = keep + __shfl_xor(send, o, 64);
+    }
   }
+  const float v = s[0] + __shfl_xor(s[0], 1, 64);
+  if ((lane & 1) == 0) {
+    const int i = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
+    const int j = wave + 8 * i;
+    const float t = v + (B ? B[j] : 0.f);
+    y[j] = relu ? fmaxf(t, 0.f) : t;
+  }
+}
+
+// one output row per wave (class head, last MLP layer): row already in registers
+__device__ __forceinline__ float dot_row(const float4 w, const float4 x) {
+  return wave_sum(fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, w.w * x.w))));
 }
 
 __global__ void __launch_bounds__(512) decode_tail_kernel(const DecTailP p) {
   __shared__ __attribute__((aligned(16))) float buf[2][256];
   __shared__ float small[8];
   const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // LN3 of this row, redundantly in every wave (no barrier): x = 4 consecutive channels per lane
+  // everything that does not depend on data is requested up front: the row, the first MLP layer's weight block, the
+  // last MLP layer's two rows and the class-head rows (one row per wave)
   float4 x = *reinterpret_cast<const float4*>(p.P4 + (long long)n * p.ldp + 4 * lane);
+  WRows wr;
+  load_rows256(wr, p.W1);
+  const float4 w3 = *reinterpret_cast<const float4*>(p.W3 + (long long)(wave & 1) * 256 + 4 * lane);
+  const float4 wc = p.Wc ? *reinterpret_cast<const float4*>(p.Wc + (long long)min(wave, p.ncls - 1) * 256 + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // LN3 of this row, redundantly in every wave (no barrier): x = 4 consecutive channels per lane
   {
     const float mean = wave_sum(x.x + x.y + x.z + x.w) / 256.f;
     const float a = x.x - mean, b = x.y - mean, c = x.z - mean, d = x.w - mean;
@@ -187,24 +223,30 @@ __global__ void __launch_bounds__(512) decode_tail_kernel(const DecTailP p) {
     x = make_float4(a * rstd * g.x + be.x, b * rstd * g.y + be.y, c * rstd * g.z + be.z, d * rstd * g.w + be.w);
   }
   if (p.hs_out && wave == 0) *reinterpret_cast<float4*>(p.hs_out + (long long)n * p.ld_hs + 4 * lane) = x;
-  if (p.Wc) wave_gemv(p.Wc, p.Bc, x, small + 2, p.ncls, false);            // class head reads the layer output
-  wave_gemv(p.W1, p.B1, x, buf[0], 256, true);
+  if (p.Wc && wave < p.ncls) {                                              // class head reads the layer output
+    const float c = dot_row(wc, x);
+    if (lane == 0) small[2 + wave] = c + p.Bc[wave];
+  }
+  gemv256(wr, p.B1, x, buf[0], true);
+  load_rows256(wr, p.W2);                                                  // in flight across the barrier
   __syncthreads();
   float4 h = *reinterpret_cast<const float4*>(&buf[0][4 * lane]);
-  wave_gemv(p.W2, p.B2, h, buf[1], 256, true);
+  gemv256(wr, p.B2, h, buf[1], true);
+  if (p.Wp) load_rows256(wr, p.Wp);                                        // next layer's pos_trans block, behind the refinement
   __syncthreads();
   h = *reinterpret_cast<const float4*>(&buf[1][4 * lane]);
-  wave_gemv(p.W3, p.B3, h, small, 2, false);
-  __syncthreads();
-  if (threadIdx.x < 2) {
-    const float z = small[threadIdx.x] + inv_sigmoid_f(p.ref[n * 2 + threadIdx.x]);
-    const float r = 1.f / (1.f + expf(-z));
-    small[threadIdx.x] = r;
-    p.ref_out[(long long)n * p.ld_ref + threadIdx.x] = r;
+  if (wave < 2) {
+    const float dlt = dot_row(w3, h);
+    if (lane == 0) {
+      const float z = dlt + p.B3[wave] + inv_sigmoid_f(p.ref[n * 2 + wave]);
+      const float r = 1.f / (1.f + expf(-z));
+      small[wave] = r;
+      p.ref_out[(long long)n * p.ld_ref + wave] = r;
+    }
   }
+  __syncthreads();
   if (p.cls_out && threadIdx.x < p.ncls) p.cls_out[(long long)n * p.ld_cls + threadIdx.x] = small[2 + threadIdx.x];
   if (!p.Wp) return;
-  __syncthreads();
   const float rx = small[0], ry = small[1];
   if (threadIdx.x < 2 * p.L) {                                               // next layer's reference points per level
     const int l = threadIdx.x >> 1, a = threadIdx.x & 1;
@@ -218,7 +260,7 @@ __global__ void __launch_bounds__(512) decode_tail_kernel(const DecTailP p) {
     const float v = ((c >> 7) ? ry : rx) * 6.283185307179586f / p.dim_t[k];
     e[i] = (k & 1) ? cosf(v) : sinf(v);
   }
-  wave_gemv(p.Wp, p.Bp, make_float4(e[0], e[1], e[2], e[3]), buf[0], 256, false);
+  gemv256(wr, p.Bp, make_float4(e[0], e[1], e[2], e[3]), buf[0], false);
   __syncthreads();
   if (wave == 0) {
     const float4 q = *reinterpret_cast<const float4*>(&buf[0][4 * lane]);
@@ -243,9 +285,10 @@ extern "C" int cape_decode_linear(const cape_decode_linear_desc* d, cape_stream_
   CAPE_REQUIRE(d->X && d->W && al16(d->X) && al16(d->W) && d->ldx % 4 == 0 && d->ldw % 4 == 0, "cape_decode_linear: X / W must be 16-byte aligned rows");
   CAPE_REQUIRE((d->in_gamma != nullptr) == (d->in_beta != nullptr) && (d->res_gamma != nullptr) == (d->res_beta != nullptr),
                "cape_decode_linear: LayerNorm parameters come in (gamma, beta) pairs");
-  if (d->in_gamma) CAPE_REQUIRE(d->K <= 1024 && al16(d->in_gamma) && al16(d->in_beta), "cape_decode_linear: LN-on-load needs K <= 1024");
+  if (d->in_gamma) CAPE_REQUIRE(d->K == 256 && al16(d->in_gamma) && al16(d->in_beta), "cape_decode_linear: LN-on-load needs K == 256 (the model width)");
   if (d->in_add) CAPE_REQUIRE(al16(d->in_add) && d->ld_add % 4 == 0, "cape_decode_linear: in_add must be 16-byte aligned rows");
-  if (d->res_gamma) CAPE_REQUIRE(d->R && d->Nout % 4 == 0 && d->Nout <= 1024 && al16(d->R) && d->ldr % 4 == 0, "cape_decode_linear: normalised residual needs aligned rows of width Nout <= 1024");
+  if (d->res_gamma) CAPE_REQUIRE(d->R && d->Nout == 256 && al16(d->R) && d->ldr % 4 == 0 && al16(d->res_gamma) && al16(d->res_beta),
+                                 "cape_decode_linear: a normalised residual needs aligned rows of width Nout == 256");
   if (d->X2) CAPE_REQUIRE(d->W2 && d->K2 > 0 && d->K2 % 4 == 0 && d->n2 > 0 && d->n2 % DL_COLS == 0 && d->n2 <= d->Nout && al16(d->X2) && al16(d->W2) &&
                           d->ldx2 % 4 == 0 && d->ldw2 % 4 == 0, "cape_decode_linear: bad second product");
   CAPE_REQUIRE(d->nseg >= 1 && d->nseg <= 3 && d->seg > 0 && d->nseg * d->seg == d->Nout, "cape_decode_linear: output segments must tile Nout");
@@ -258,10 +301,10 @@ extern "C" int cape_decode_linear(const cape_decode_linear_desc* d, cape_stream_
   p.R = d->R; p.ldr = d->ldr; p.res_gamma = d->res_gamma; p.res_beta = d->res_beta;
   p.relu = d->relu; p.nseg = d->nseg; p.seg = d->seg;
   for (int i = 0; i < 3; ++i) { p.out[i] = i < d->nseg ? d->out[i] : nullptr; p.ldo[i] = i < d->nseg ? d->ldo[i] : 0; }
-  const size_t lds = ((size_t)(d->N + DL_COLS) * (DL_KC + 4) + 4 * (size_t)d->N) * sizeof(float);
+  const size_t lds = ((size_t)(2 * d->N + DL_COLS) * (DL_KC + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {                                 // N = 64 rows needs 75 KB: opt in once for the maximum
-    const size_t max_lds = ((size_t)(DL_MAXN + DL_COLS) * (DL_KC + 4) + 4 * (size_t)DL_MAXN) * sizeof(float);
+    const size_t max_lds = ((size_t)(2 * DL_MAXN + DL_COLS) * (DL_KC + 4)) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return cape_set_error("cape_decode_linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;

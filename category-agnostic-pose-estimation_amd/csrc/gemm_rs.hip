@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
     // = 64 lanes x 16 bytes, so the whole weight block of this wave arrives as 2 * K/16 coalesced 1 KB loads -- no LDS pass,
     // no split arithmetic, no barrier before the first MFMA
     load_rows(ra, p.A, p.lda, slot * RS_UNIT, p.M);
-    const uint4* bp = reinterpret_cast<const uint4*>(p.Bpack) + ((long long)(n0 >> 5) * KS * 2) * 64 + lane;
+    // (a wave whose 32 columns lie entirely beyond N reads the last packed group: valid memory, results never stored)
+    const int grp = min(n0 >> 5, (p.N + 31) / 32 - 1);
+    const uint4* bp = reinterpret_cast<const uint4*>(p.Bpack) + ((long long)grp * KS * 2) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       bhi[s] = __builtin_bit_cast(bf16x8, bp[(2 * s + 0) * 64]);

@@ -36,6 +36,13 @@ int main(int argc, char** argv) {
   if (gen == 2) { fill<<<(unsigned)(((long long)M * N + 255) / 256), 256>>>(R, (long long)M * N, 3); p.mask_src = R; p.ldm = N; p.mask_scale = 1.f; }
   if (gen == 3) { p.accumulate = 1; }
   if (gen == 4) { uint64_t* st8; hipMalloc(&st8, 16); uint64_t hs[2] = {1234, 5}; hipMemcpy(st8, hs, 16, hipMemcpyHostToDevice); p.rng_state = st8; p.rng_stream = 3; p.drop_thresh = cape_drop_threshold(0.1f); p.inv_keep = 1.f / 0.9f; p.relu = 1; }
+  if (getenv("RS_LAB_PACKED")) {
+    unsigned short* pk; hipMalloc(&pk, cape_packed_weight_bytes(N, K));
+    cape_pack_item it = {B, pk, (long long)(bm == 0 ? K : N), N, K, bm, 0};
+    cape_pack_item* itd; hipMalloc(&itd, sizeof(it)); hipMemcpy(itd, &it, sizeof(it), hipMemcpyHostToDevice);
+    if (cape_pack_weights(itd, 1, 16, 0)) { printf("pack error: %s\n", cape_last_error()); return 1; }
+    p.Bpack = pk;
+  }
   if (!cape_gemm_rs_eligible(p, 0, bm)) { printf("not eligible\n"); return 1; }
 #ifdef RS_STAMPS
   long long* st; hipMalloc(&st, 8 * 16 * 4096); hipMemset(st, 0, 8 * 16 * 4096);
