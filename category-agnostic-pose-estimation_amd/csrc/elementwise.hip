@@ -112,6 +112,23 @@ __global__ void bn_relu_bwd_kernel(const float* dy, const float* y, const float*
   }
 }
 
+// in place: x = [relu]( x * scale[c] + bias[c] [+ residual] ) -- the FrozenBN / ReLU / shortcut epilogue of a convolution whose
+// contraction was split over k (atomic partial sums cannot carry an epilogue)
+__global__ void affine_act_kernel(float* x, const float* scale, const float* bias, const float* residual, long long rows, int C,
+                                  int relu) {
+  const int C4 = C >> 2;
+  const long long tot = rows * C4;
+  GSTRIDE(i, tot) {
+    const int c = (int)(i % C4) * 4;
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    if (scale) { const float4 s = *reinterpret_cast<const float4*>(scale + c); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (residual) { const float4 r = reinterpret_cast<const float4*>(residual)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+
 __global__ void relu_drop_bwd_kernel(const float* dh, const float* h, float* d_pre, long long n, float inv_keep) {
   GSTRIDE(i, n) d_pre[i] = h[i] > 0.f ? dh[i] * inv_keep : 0.f;
 }
@@ -376,6 +393,18 @@ extern "C" int cape_bn_relu_bwd(const float* dy, const float* y, const float* sc
   if (n == 0) return 0;
   LAUNCH1(bn_relu_bwd_kernel, n, 1, dy, y, scale, d_pre, d_res, rows, C, relu);
   CAPE_LAUNCH_CHECK("cape_bn_relu_bwd");
+  return 0;
+}
+
+extern "C" int cape_affine_act_f32(float* x, const float* scale, const float* bias, const float* residual, long long rows, int C,
+                                   int relu, cape_stream_t stream) {
+  CAPE_REQUIRE(x && rows >= 0 && C > 0 && C % 4 == 0, "cape_affine_act_f32: bad arguments (C must be a multiple of 4)");
+  CAPE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) |
+                 reinterpret_cast<uintptr_t>(residual)) & 15) == 0, "cape_affine_act_f32: pointers must be 16-byte aligned");
+  const long long n = rows * (C / 4);
+  if (n == 0) return 0;
+  LAUNCH1(affine_act_kernel, n, 1, x, scale, bias, residual, rows, C, relu);
+  CAPE_LAUNCH_CHECK("cape_affine_act_f32");
   return 0;
 }
 

@@ -1,7 +1,7 @@
-"""Input contract of the CAPE hot path (tokenisation, episodic collation, synthetic episodes).  The
-MP-100 file loaders of the reference (`datasets/mp100_cape.py` image I/O, pycocotools, albumentations)
-are host I/O outside the hot path."""
+"""Input side of the CAPE path: tokenisation, episodic sampling / collation, the MP-100 file loader (COCO-style annotations
+read by a pure-Python reader, transforms as plans that run on the host or on the GPU) and seeded synthetic episodes."""
 from .discrete_tokenizer import DiscreteTokenizer, DiscreteTokenizerV2
-from .episodic_sampler import episodic_collate_fn
+from .episodic_sampler import EpisodicDataset, EpisodicSampler, build_episodic_dataloader, episodic_collate_fn
 from .keypoint_tokenization import tokenize_keypoints
 from .token_types import TokenType
+from .mp100_cape import ImageNotFoundError, MP100CAPE, build_mp100_cape

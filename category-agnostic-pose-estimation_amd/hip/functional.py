@@ -4,11 +4,12 @@ Each `torch.autograd.Function` here is glue: forward and backward only *launch* 
 libcape_hip.so (through `ops`) and keep the tensors backward needs.  No arithmetic of the hot path is
 done by torch ops in this file.
 """
+import ctypes
 import os
 
 import torch
 
-from . import ops
+from . import lib, ops
 
 
 class Runtime:
@@ -25,17 +26,22 @@ class Runtime:
     on_param_grad = []
     capture_keep = None          # list while a hipGraph capture is in progress (runtime/graph_step.py)
 
+    pending = []                 # tensors read by enqueued side-stream kernels: kept alive until join()
+
     @classmethod
     def side_stream(cls):
         if cls.side is None:
             cls.side = torch.cuda.Stream()
+            cls.side_raw = cls.side.cuda_stream
         return cls.side
 
     @classmethod
     def join(cls):
         """Make the current stream wait for all enqueued side-stream work (call before the optimizer step)."""
         if cls.side is not None:
-            torch.cuda.current_stream().wait_stream(cls.side)
+            lib.call("cape_stream_join", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(cls.side_raw))
+            if cls.capture_keep is None:
+                cls.pending.clear()
 
     @classmethod
     def notify(cls, *params):
@@ -85,8 +91,9 @@ def _param_of(p):
 
 
 class _Side:
-    """with _Side(tensors...): kernels inside run on the side stream, ordered after the current stream's work so
-    far; the listed tensors are kept alive for that stream."""
+    """with _Side(tensors...): kernels launched inside go to the side stream, ordered after the current stream's work so far
+    (one C call: event record + wait; no framework stream switch); the listed tensors are kept alive until the next join --
+    the caching allocator may otherwise hand their blocks to a later main-stream kernel while the side kernel still reads them."""
 
     def __init__(self, *tensors):
         self.tensors = [t for t in tensors if t is not None]
@@ -95,23 +102,18 @@ class _Side:
         self.on = Runtime.use_side_stream
         if not self.on:
             return self
-        self.s = Runtime.side_stream()
-        self.s.wait_stream(torch.cuda.current_stream())
-        self.ctx = torch.cuda.stream(self.s)
-        self.ctx.__enter__()
+        Runtime.side_stream()
+        lib.call("cape_stream_fork", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(Runtime.side_raw))
+        ops._stream_override[0] = Runtime.side_raw
         return self
 
     def __exit__(self, *a):
         if not self.on:
             return False
-        self.ctx.__exit__(*a)
-        if Runtime.capture_keep is not None:
-            # graph capture: the allocator must not hand these blocks out again inside the captured step (there is no
-            # edge from the side-stream reader to a later main-stream writer); keep them alive until capture ends
-            Runtime.capture_keep.extend(self.tensors)
-        else:
-            for t in self.tensors:
-                t.record_stream(self.s)
+        ops._stream_override[0] = None
+        (Runtime.capture_keep if Runtime.capture_keep is not None else Runtime.pending).extend(self.tensors)
+        if len(Runtime.pending) > 8192:                 # a caller that never joins (backward without an optimizer step)
+            Runtime.join()
         return False
 
 
@@ -304,7 +306,7 @@ def _w_phys(weight):
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu):
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu, allow_split=False):
         # x (N, H, W, C) contiguous NHWC
         x = _c(x)
         N, H, W, C = x.shape
@@ -317,19 +319,26 @@ class ConvFn(torch.autograd.Function):
         res = _c(residual) if residual is not None else None
         geom = (N, H, W, C, KH, KW, stride, pad, OH, OW, O)
         dense = KH == 1 and KW == 1 and stride == 1 and pad == 0
-        # few output tiles over a deep contraction (the 3x3/s2 input_proj conv on C5: 512 x 256 x 18432 = 32 tiles): split K,
-        # the bias rides with the first split (no BN / ReLU / residual on these convolutions)
-        # (training only: the atomic k-split sums in arrival order, and inference keeps run-to-run bitwise reproducibility --
-        # the replayed decode graphs are tested bit-for-bit against the eager loop)
-        sk = ops.pick_split_k(M, O, K) if (scale is None and res is None and not relu and torch.is_grad_enabled()) else 1
-        sk = sk if sk >= 8 else 1
+        # few output tiles over a deep contraction (the 3x3/s2 input_proj conv on C5: 512 x 256 x 18432 = 32 tiles; the 3x3
+        # convolutions of layer4: 2048 x 512 x 4608 = 256 tiles of 144 k-tiles each): split K over blocks (atomic partial sums,
+        # the bias rides with the first split) and apply FrozenBN / ReLU / shortcut in a separate in-place pass.  Training
+        # only: the atomic k-split sums in arrival order, and inference keeps run-to-run bitwise reproducibility (the
+        # replayed decode graphs are tested bit-for-bit against the eager loop).
+        # (`allow_split` = grad mode at the call site: autograd runs Function.forward itself with grad mode off)
+        sk = ops.pick_split_k(M, O, K) if allow_split else 1
+        plain = scale is None and res is None and not relu
+        sk = sk if (sk >= 8 or (sk >= 4 and not plain)) else 1
         if sk > 1:
             y.zero_()
-        kw = dict(bias=shift, split_k=sk, accumulate=True) if sk > 1 else dict(scale=scale, bias=shift, residual=res, relu=relu)
+            kw = dict(bias=shift if plain else None, split_k=sk, accumulate=True)
+        else:
+            kw = dict(scale=scale, bias=shift, residual=res, relu=relu)
         if dense:
             ops.gemm(x, wp, y, M, O, K, **kw)
         else:
             ops.gemm(x, wp, y, M, O, K, a_mode=2, b_mode=0, conv=geom, **kw)
+        if sk > 1 and not plain:
+            ops.affine_act_(y, scale, shift, res, relu)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
         ctx.w_ref, ctx.shift_ref = weight, shift
         ctx.meta = (geom, dense, relu, shift is not None, residual is not None)
@@ -355,7 +364,11 @@ class ConvFn(torch.autograd.Function):
             if dense:
                 ops.gemm(dpre, wp, dx, M, C, O, a_mode=0, b_mode=1)
             else:
-                ops.gemm(dpre, wp, dx, N * H * W, C, KH * KW * O, a_mode=3, b_mode=2, conv=geom)
+                sk = ops.pick_split_k(N * H * W, C, KH * KW * O)
+                sk = sk if sk >= 4 else 1
+                if sk > 1:
+                    dx.zero_()
+                ops.gemm(dpre, wp, dx, N * H * W, C, KH * KW * O, a_mode=3, b_mode=2, conv=geom, split_k=sk, accumulate=sk > 1)
         wsink = _sink(ctx.w_ref)
         ssink = _sink(ctx.shift_ref) if (has_shift and ctx.needs_input_grad[3]) else None
         need_w = ctx.needs_input_grad[1]
@@ -388,7 +401,7 @@ class ConvFn(torch.autograd.Function):
         if need_s and ssink is None:
             dshift = torch.zeros(O, dtype=torch.float32, device=dy.device)
             ops.colsum(src_s, M, O, dshift)
-        return dx, dw, None, dshift, dres, None, None, None
+        return dx, dw, None, dshift, dres, None, None, None, None
 
 
 def _relu_bwd_noscale(dy, y, relu, want_res):
@@ -403,7 +416,7 @@ def _mask_only(dy, y, relu):
 
 
 def conv_bn_act(x, weight, scale, shift, stride=1, pad=0, relu=False, residual=None):
-    return ConvFn.apply(x, weight, scale, shift, residual, int(stride), int(pad), bool(relu))
+    return ConvFn.apply(x, weight, scale, shift, residual, int(stride), int(pad), bool(relu), torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------

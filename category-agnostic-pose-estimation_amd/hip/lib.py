@@ -81,6 +81,8 @@ class DecodeTailDesc(ctypes.Structure):
 P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
 _SIGS = {
     "cape_rng_advance": [P, P],
+    "cape_stream_fork": [P, P],
+    "cape_stream_join": [P, P],
     "cape_gemm_f32": [POINTER(GemmDesc), P],
     "cape_pack_weights": [P, I, I, P],
     "cape_colsum_f32": [P, LL, I, LL, I, I, P, I, P],
@@ -103,6 +105,7 @@ _SIGS = {
     "cape_bn_fold": [P, P, P, P, F, P, P, I, P],
     "cape_maxpool3x3s2_nhwc": [P, P, I, I, I, I, P],
     "cape_bn_relu_bwd": [P, P, P, P, P, LL, I, I, P],
+    "cape_affine_act_f32": [P, P, P, P, LL, I, I, P],
     "cape_relu_drop_bwd": [P, P, P, LL, F, P],
     "cape_pos_sine_level": [P, P, P, P, LL, I, I, I, I, P],
     "cape_token_embed_fwd": [P, P, P, P, P, P, P, P, P, P, LL, I, I, P],

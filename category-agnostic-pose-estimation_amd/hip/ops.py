@@ -20,10 +20,21 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_stream_override = [None]        # set by hip/functional._Side: launches go to the weight-gradient side stream
+
+
+def raw_current_stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    """hipStream_t of torch's current stream on the current device.  The two private C entry points cost ~0.5 us; the public
+    """hipStream_t of torch's current stream on the current device (or the side stream while hip/functional._Side is active).  The two private C entry points cost ~0.5 us; the public
     torch.cuda.current_stream().cuda_stream walks Python helpers for ~8 us -- 40 % of a launcher's host time, ~6 ms per
     training step (1250 launches)."""
+    if _stream_override[0] is not None:
+        return ctypes.c_void_p(_stream_override[0])
     if _raw_stream is not None and _raw_device is not None:
         return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -556,6 +567,15 @@ def bn_relu_bwd(dy, y, scale, relu, want_res):
     d_res = torch.empty_like(dy) if want_res else None
     lib.call("cape_bn_relu_bwd", _p(dy), _p(y), _p(scale), _p(d_pre), _p(d_res), rows, C, int(relu), _stream())
     return d_pre, d_res
+
+
+def affine_act_(x, scale, bias, residual, relu):
+    """In place x = [relu](x * scale + bias [+ residual]) over the last dimension."""
+    _chk(x, "affine_act.x"); _chk(scale, "affine_act.scale"); _chk(bias, "affine_act.bias"); _chk(residual, "affine_act.residual")
+    C = x.shape[-1]
+    assert (scale is None or scale.numel() == C) and (bias is None or bias.numel() == C) and (residual is None or residual.shape == x.shape)
+    lib.call("cape_affine_act_f32", _p(x), _p(scale), _p(bias), _p(residual), x.numel() // C, C, int(relu), _stream())
+    return x
 
 
 def relu_drop_bwd(dh, h, inv_keep):

@@ -266,9 +266,6 @@ def run_training(args):
     torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
     HF.Runtime.seed(seed, device)
     Path(args.output_dir).mkdir(parents=True, exist_ok=True)
-    if args.dataset_name != "synthetic":
-        raise RuntimeError("the MP-100 file loader is host I/O outside the hot path; run with --dataset_name synthetic "
-                           "(seeded MP-100-shaped episodes) or plug a loader that yields episodic_collate_fn batches")
     tok = DiscreteTokenizerV2(num_bins=int(math.sqrt(args.vocab_size)), seq_len=args.seq_len, add_cls=False)
     base, _ = build_model(args, tokenizer=tok)
     criterion = build_cape_criterion(args, num_classes=3).to(device)
@@ -276,9 +273,23 @@ def run_training(args):
     if args.batch_size % world:
         raise ValueError(f"--batch_size {args.batch_size} (episodes per global batch) must be divisible by the world size {world}")
     per_rank = args.batch_size // world
-    res = 512 if args.image_size == 512 else args.image_size
-    train_ds = SyntheticEpisodes(tok, args.episodes_per_epoch, res, 17, args.num_queries_per_episode, seed=args.seed)
-    val_ds = SyntheticEpisodes(tok, args.val_episodes_per_epoch, res, 17, args.num_queries_per_episode, seed=args.val_seed + 999)
+    if args.dataset_name == "synthetic":
+        res = 512 if args.image_size == 512 else args.image_size
+        train_ds = SyntheticEpisodes(tok, args.episodes_per_epoch, res, 17, args.num_queries_per_episode, seed=args.seed)
+        val_ds = SyntheticEpisodes(tok, args.val_episodes_per_epoch, res, 17, args.num_queries_per_episode, seed=args.val_seed + 999)
+    else:
+        # MP-100 files (reference train_cape_episodic.py:351-354, :417, :465-516): COCO-style annotations under --dataset_root,
+        # episodes of one category each; validation on the unseen categories with batch size 1
+        from ..datasets import EpisodicDataset, build_mp100_cape
+        split_file = str(Path(args.dataset_root) / args.category_split_file)
+        train_ds = EpisodicDataset(build_mp100_cape("train", args), split_file, split="train",
+                                   num_queries_per_episode=args.num_queries_per_episode, episodes_per_epoch=args.episodes_per_epoch,
+                                   seed=args.seed, load_support_images=False)
+        fixed_val = getattr(args, "fixed_val_episodes", False)
+        val_ds = EpisodicDataset(build_mp100_cape("val", args), split_file, split="val",
+                                 num_queries_per_episode=args.num_queries_per_episode, episodes_per_epoch=args.val_episodes_per_epoch,
+                                 seed=(args.val_seed if fixed_val else args.seed + 999), fixed_episodes=fixed_val,
+                                 load_support_images=False)
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds, world, rank, shuffle=False) if world > 1 else None
     vsampler = torch.utils.data.distributed.DistributedSampler(val_ds, world, rank, shuffle=False) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_ds, per_rank, sampler=sampler, collate_fn=episodic_collate_fn,

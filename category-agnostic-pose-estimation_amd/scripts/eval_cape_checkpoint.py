@@ -10,8 +10,8 @@ stored training `args` (the tokenizer from `vocab_size` / `seq_len`, as `mp100_c
 `state_dict` (the keys of the reference; the "contaminated" `support_cross_attn_layers.*` / `support_attn_norms.*` keys of old
 reference checkpoints are reported and ignored like the reference does), runs `evaluate_cape` (KV-cached autoregressive decode,
 PCK@bbox) and writes `metrics.json`.  The visualisation flags of the reference are accepted and ignored: drawing needs the
-MP-100 images, and the MP-100 file loader is host I/O outside this package -- episodes come from
-`--dataset_name synthetic` (seeded MP-100-shaped episodes) unless a loader yielding `episodic_collate_fn` batches is plugged in.
+image files on disk and matplotlib / cv2, which this package does not depend on.  Episodes come from the dataset the
+checkpoint was trained on: MP-100 files (`datasets/mp100_cape.py`, `--dataset-root` to relocate) or `--dataset_name synthetic`.
 """
 import argparse
 import json
@@ -84,8 +84,14 @@ def build_dataloader(args, tok, split, num_workers, num_episodes=None, num_queri
     from ..datasets import episodic_collate_fn
     from ..datasets.synthetic import SyntheticEpisodes
     if getattr(args, "dataset_name", "synthetic") != "synthetic":
-        raise RuntimeError("the MP-100 file loader is host I/O outside this package (SURVEY 8 row f2); evaluate with a checkpoint "
-                           "trained with --dataset_name synthetic or plug a loader that yields episodic_collate_fn batches")
+        # MP-100 files: the checkpoint's dataset_root (or --dataset-root) holds the annotations, images and category_splits.json
+        from ..datasets import EpisodicDataset, build_mp100_cape
+        K = num_queries if num_queries is not None else args.num_queries_per_episode
+        n = num_episodes if num_episodes is not None else args.val_episodes_per_epoch
+        ds = EpisodicDataset(build_mp100_cape(split, args), str(Path(args.dataset_root) / args.category_split_file), split=split,
+                             num_queries_per_episode=K, episodes_per_epoch=n, seed=eval_seed, fixed_episodes=True,
+                             load_support_images=False)
+        return torch.utils.data.DataLoader(ds, 1, shuffle=False, collate_fn=episodic_collate_fn, num_workers=num_workers, pin_memory=True)
     n = num_episodes if num_episodes is not None else {"train": args.episodes_per_epoch, "val": args.val_episodes_per_epoch,
                                                        "test": args.val_episodes_per_epoch}[split]
     K = num_queries if num_queries is not None else args.num_queries_per_episode

@@ -35,6 +35,11 @@ int cape_abi_version(void);
  * ---------------------------------------------------------------------------------------------- */
 int cape_rng_advance(uint64_t* rng_state, cape_stream_t stream);
 
+/* Two-stream ordering for the weight-gradient side stream (runtime of this package; the reference is single-stream):
+ * fork = side_stream continues after everything enqueued on main_stream so far, join = the converse.  Graph-capturable. */
+int cape_stream_fork(cape_stream_t main_stream, cape_stream_t side_stream);
+int cape_stream_join(cape_stream_t main_stream, cape_stream_t side_stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM family on fp32 MFMA (v_mfma_f32_32x32x2_f32):  C[M,N] (+)= epi(A[M,K] * B[K,N])
  *
@@ -271,6 +276,10 @@ int cape_maxpool3x3s2_nhwc(const float* x, float* out, int N, int H, int W, int 
  * d_res = dy * (y > 0) (optional).  relu == 0 skips the mask.  rows x C, C % 4 == 0. */
 int cape_bn_relu_bwd(const float* dy, const float* y, const float* scale, float* d_pre, float* d_res,
                      long long rows, int C, int relu, cape_stream_t stream);
+/* in place: x = [relu](x * scale[c] + bias[c] [+ residual]) over (rows, C): FrozenBatchNorm2d affine + ReLU + shortcut
+ * (backbone.py:32-40, torchvision Bottleneck) as a separate pass, for convolutions whose contraction was split over k. */
+int cape_affine_act_f32(float* x, const float* scale, const float* bias, const float* residual, long long rows, int C, int relu,
+                        cape_stream_t stream);
 /* d_pre = dh * (h > 0) * inv_keep  (backward of relu+dropout fused in a GEMM epilogue) */
 int cape_relu_drop_bwd(const float* dh, const float* h, float* d_pre, long long n, float inv_keep,
                        cape_stream_t stream);
