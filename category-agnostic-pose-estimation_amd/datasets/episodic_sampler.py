@@ -132,6 +132,7 @@ def episodic_collate_fn(batch):
         pc.append(c); pm.append(m)
     B = len(batch)
     K = len(q_imgs) // B
+    deferred = bool(q_imgs) and isinstance(q_imgs[0], tuple)
     sc = torch.stack(pc).view(B, n_sup, P, 2).mean(1)
     sm = torch.stack(pm).view(B, n_sup, P).any(1)
     support_images = None
@@ -146,8 +147,8 @@ def episodic_collate_fn(batch):
         "support_skeletons": [s for s in first_skel for _ in range(K)],
         "support_metadata": [meta[i * n_sup] for i in range(B) for _ in range(K)],
         # deferred pixels (MP100CAPE(defer_pixels=True)): raw uint8 crops + plans travel, transforms.DeviceImagePipeline makes the batch
-        "query_images": torch.stack(q_imgs) if not (q_imgs and isinstance(q_imgs[0], tuple)) else None,
-        "query_raw": q_imgs if (q_imgs and isinstance(q_imgs[0], tuple)) else None,
+        "query_images": torch.stack(q_imgs) if not deferred else None,
+        **({"query_raw": q_imgs} if deferred else {}),
         "query_targets": {k: torch.stack([t[k] for t in q_tgts]) for k in q_tgts[0]},
         "query_metadata": q_meta,
         "category_ids": torch.tensor(cats, dtype=torch.long).repeat_interleave(K),
