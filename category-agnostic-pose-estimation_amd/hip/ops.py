@@ -87,8 +87,13 @@ def new_stream_id():
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+_NO_SPLIT_K = os.environ.get("CAPE_NO_SPLIT_K") is not None       # diagnostics: deterministic k order everywhere
+
+
 def pick_split_k(M, N, K):
     """Enough tiles to fill 256 CUs about twice; each split keeps >= 8 k-tiles of 32."""
+    if _NO_SPLIT_K:
+        return 1
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     ktiles = (K + 31) // 32
     want = max(1, 1024 // max(tiles, 1))
