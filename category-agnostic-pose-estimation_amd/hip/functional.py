@@ -440,6 +440,7 @@ class AddLayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, y, gamma, mean, rstd)
         ctx.refs = (gamma, beta)
         ctx.meta = (dropout_p, rng_stream, pos is not None)
+        ctx.set_materialize_grads(False)        # an unused output arrives as None, not as a zero-filled tensor
         if pos is None:
             return out
         return out, out_pos
@@ -448,9 +449,11 @@ class AddLayerNormFn(torch.autograd.Function):
     def backward(ctx, d_out, d_out_pos=None):
         x, y, gamma, mean, rstd = ctx.saved_tensors
         p, stream, has_pos = ctx.meta
+        g_pos = d_out_pos                       # out_pos = out + pos: its gradient reaches `pos` unchanged
+        if d_out is None and d_out_pos is None:
+            return None, None, None, None, None, None, None
         if d_out is None:
             d_out, d_out_pos = d_out_pos, None
-            d_pos_only = d_out
         d_out, d_out_pos = _c(d_out), _c(d_out_pos)
         C = x.shape[-1]
         gs, bs = _sink(ctx.refs[0]), _sink(ctx.refs[1])
@@ -463,9 +466,7 @@ class AddLayerNormFn(torch.autograd.Function):
         if direct:
             Runtime.notify(_param_of(ctx.refs[0]), _param_of(ctx.refs[1]))
             dg = db = None
-        dpos = None
-        if has_pos and ctx.needs_input_grad[4]:
-            dpos = d_out_pos if d_out_pos is not None else None
+        dpos = g_pos if (has_pos and ctx.needs_input_grad[4]) else None
         return dx, (dy if y is not None else None), dg, db, dpos, None, None
 
 
@@ -495,6 +496,7 @@ class FanOutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
         ctx.k = k
+        ctx.set_materialize_grads(False)
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod
@@ -859,10 +861,13 @@ class SupportEmbedFn(torch.autograd.Function):
         ctx.refs = (W0, b0)
         ctx.meta = (N, P, C)
         ctx.mark_non_differentiable(pe)
+        ctx.set_materialize_grads(False)
         return h.view(N, P, C), pe.view(N, P, C)
 
     @staticmethod
     def backward(ctx, d_h, _d_pe):
+        if d_h is None:
+            return None, None, None, None
         h, coords = ctx.saved_tensors
         N, P, C = ctx.meta
         ws, bs = _sink(ctx.refs[0]), _sink(ctx.refs[1])
@@ -932,10 +937,13 @@ class LossFn(torch.autograd.Function):
                                                  _c(target).view(-1, 2), class_w, w_ce, w_l1, 1.0)
         ctx.save_for_backward(dl, dc)
         ctx.mark_non_differentiable(losses)
+        ctx.set_materialize_grads(False)
         return total.view(()), losses
 
     @staticmethod
     def backward(ctx, g_total, _g_losses):
+        if g_total is None:
+            return (None,) * 8
         dl, dc = ctx.saved_tensors
         # scaling by the incoming scalar gradient is glue (1/accumulation_steps)
         return dl * g_total, dc * g_total, None, None, None, None, None, None

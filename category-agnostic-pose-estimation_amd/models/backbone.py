@@ -15,7 +15,7 @@ from torch import nn
 
 from ..hip import functional as HF
 from ..hip import ops
-from ..util.misc import NestedTensor
+from ..util.misc import NestedTensor, cached_zero_mask
 from .position_encoding import build_position_encoding
 
 
@@ -82,12 +82,12 @@ class Bottleneck(nn.Module):
         s1, b1 = self.bn1.folded()
         s2, b2 = self.bn2.folded()
         s3, b3 = self.bn3.folded()
+        x, idt = HF.fanout(x, 2)                  # two consumers: their gradients are summed by one cape_add_n_f32 pass
         out = HF.conv_bn_act(x, self.conv1.weight, s1, b1, 1, 0, relu=True)
         out = HF.conv_bn_act(out, self.conv2.weight, s2, b2, self.stride, 1, relu=True)
-        idt = x
         if self.downsample is not None:
             sd, bd = self.downsample[1].folded()
-            idt = HF.conv_bn_act(x, self.downsample[0].weight, sd, bd, self.stride, 0, relu=False)
+            idt = HF.conv_bn_act(idt, self.downsample[0].weight, sd, bd, self.stride, 0, relu=False)
         # relu(bn3(conv3(out)) + identity) in one epilogue
         return HF.conv_bn_act(out, self.conv3.weight, s3, b3, 1, 0, relu=True, residual=idt)
 
@@ -146,9 +146,9 @@ class ResNet50Body(nn.Module):
                 x = self.layer1(x)
         if not frozen1:
             x = self.layer1(x)
-        c3 = self.layer2(x)
-        c4 = self.layer3(c3)
-        c5 = self.layer4(c4)
+        c3, c3n = HF.fanout(self.layer2(x), 2)    # each level also feeds the next stage
+        c4, c4n = HF.fanout(self.layer3(c3n), 2)
+        c5 = self.layer4(c4n)
         return [c3, c4, c5]
 
 
@@ -173,6 +173,10 @@ class BackboneBase(nn.Module):
             feats = feats[-1:]
         out = {}
         m = tensor_list.mask
+        if getattr(tensor_list, "no_padding", False):       # equally sized images: the resampled mask is all-False at every level
+            for i, x in enumerate(feats):
+                out[str(i)] = NestedTensor(x, cached_zero_mask(x.shape[0], x.shape[1], x.shape[2], x.device))
+            return out
         for i, x in enumerate(feats):
             # nearest-neighbour mask resize (F.interpolate default): index floor(i * H / h)
             h, w = x.shape[1], x.shape[2]

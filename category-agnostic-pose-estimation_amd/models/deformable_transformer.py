@@ -104,6 +104,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return HF.add_layernorm(src_r, h, self.norm2.weight, self.norm2.bias, pos=pos, dropout_p=p, rng_stream=self._streams[2])
 
 
+_REF_POINTS = {}        # (level shapes, N, device) -> encoder reference points of an unpadded batch (read-only)
+
+
 class DeformableTransformerEncoder(nn.Module):
     def __init__(self, encoder_layer, num_layers):
         super().__init__()
@@ -128,7 +131,13 @@ class DeformableTransformerEncoder(nn.Module):
 
     def forward(self, src, geo, valid_ratios, pos, padding_rows_u8=None):
         with torch.no_grad():
-            reference_points = self.get_reference_points(geo, valid_ratios, src.device)
+            if padding_rows_u8 is None:           # unpadded batch: valid ratios are exactly 1, the grid is a constant of the geometry
+                key = (tuple(geo.shapes), src.shape[0], str(src.device))
+                reference_points = _REF_POINTS.get(key)
+                if reference_points is None:
+                    reference_points = _REF_POINTS[key] = self.get_reference_points(geo, valid_ratios, src.device)
+            else:
+                reference_points = self.get_reference_points(geo, valid_ratios, src.device)
         poss = HF.fanout(pos, len(self.layers) + 1)
         output, src0 = HF.fanout(src, 2)
         out_pos = HF.add(src0, poss[0])

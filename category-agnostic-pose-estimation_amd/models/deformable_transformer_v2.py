@@ -22,7 +22,10 @@ from torch.nn.init import normal_
 from ..hip import functional as HF
 from ..hip import ops
 from .deformable_transformer import (DeformableTransformerEncoder, DeformableTransformerEncoderLayer, MSDeformAttn)
+from ..util.misc import cached_zero_mask
 from .kv_cache import KVCache, VCache
+
+_ONES_VR = {}          # (N, levels, device) -> valid ratios of an unpadded batch (read-only)
 
 
 def Embedding(num_embeddings, embedding_dim, padding_idx=None, zero_init=False):
@@ -414,11 +417,20 @@ class DeformableTransformer(nn.Module):
         Returns the encoder cache dict."""
         geo = ops.LevelGeometry([(s.shape[1], s.shape[2]) for s in srcs_nhwc])
         src_flatten = HF.level_groupnorm(geo, srcs_nhwc, gn_params[0], gn_params[1])
-        masks_u8 = [m.to(torch.uint8).contiguous() for m in masks]
+        if has_padding:
+            masks_u8 = [m.to(torch.uint8).contiguous() for m in masks]
+            with torch.no_grad():
+                valid_ratios = torch.stack([self.valid_ratio(m) for m in masks], 1).contiguous()
+                pad_rows = torch.cat([m.flatten(1) for m in masks_u8], 1).contiguous()
+        else:       # all-False masks: uint8 zeros and valid ratios of exactly 1 (sum(~mask) / H = H / H), one tensor per geometry
+            N = srcs_nhwc[0].shape[0]
+            masks_u8 = [cached_zero_mask(N, s.shape[1], s.shape[2], s.device, torch.uint8) for s in srcs_nhwc]
+            key = (N, len(masks), str(srcs_nhwc[0].device))
+            valid_ratios = _ONES_VR.get(key)
+            if valid_ratios is None:
+                valid_ratios = _ONES_VR[key] = torch.ones(N, len(masks), 2, dtype=torch.float32, device=srcs_nhwc[0].device)
+            pad_rows = None
         pos = HF.level_pos(geo, self.level_embed, masks_u8)
-        with torch.no_grad():
-            valid_ratios = torch.stack([self.valid_ratio(m) for m in masks], 1).contiguous()
-            pad_rows = torch.cat([m.flatten(1) for m in masks_u8], 1).contiguous() if has_padding else None
         memory = self.encoder(src_flatten, geo, valid_ratios, pos, pad_rows)
         return {"memory": memory, "geo": geo, "valid_ratios": valid_ratios, "pad_rows": pad_rows, "src_flatten": src_flatten}
 

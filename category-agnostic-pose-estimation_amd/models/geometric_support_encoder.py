@@ -75,9 +75,10 @@ class GeometricSupportEncoder(nn.Module):
         zero = all_masked[:, None].expand(bs, num_pts)
         if fast:
             zero = zero | mask
-        # (host decision on a tiny bool tensor; one sync per call like the reference's `.any()`)
-        if HF.capturing() or bool(zero.any()):        # inside a graph capture: always run the (then no-op) kernel
-            x = HF.zero_rows(x, zero.reshape(-1).to(torch.uint8).contiguous())
+        # the reference branches on `.any()` (geometric_support_encoder.py:218): that is a device->host sync per step, which
+        # stops the host from enqueueing ahead of the GPU; the row-zeroing kernel is a no-op when no row is flagged, so it runs
+        # unconditionally instead
+        x = HF.zero_rows(x, zero.reshape(-1).to(torch.uint8).contiguous())
         return x
 
     def __repr__(self):

@@ -13,7 +13,7 @@ from torch import nn
 
 from ..hip import functional as HF
 from ..hip import ops
-from ..util.misc import NestedTensor, nested_tensor_from_tensor_list
+from ..util.misc import NestedTensor, cached_zero_mask, nested_tensor_from_tensor_list
 from .backbone import Conv2dCL, build_backbone
 from .deformable_transformer_v2 import (DecodeWeights, alloc_decode_workspace, build_deforamble_transformer, decode_step_fused)
 from .kv_cache import KVCache, VCache
@@ -119,22 +119,32 @@ class RoomFormerV2(nn.Module):
             samples = nested_tensor_from_tensor_list(samples)
         elif samples.mask is not None:
             has_padding = True if HF.capturing() else bool(samples.mask.any())     # no host sync inside a graph capture
+        if not has_padding:
+            samples.no_padding = True            # equally sized images: every resampled mask below is the cached all-False one
         features = self.backbone(samples)
         srcs, masks = [], []
         last = None
+
+        def level_mask(mask, src):
+            if not has_padding:
+                return cached_zero_mask(src.shape[0], src.shape[1], src.shape[2], src.device)
+            return _nearest_mask(mask, src.shape[1], src.shape[2])
+
         for l, feat in enumerate(features):
             x, mask = feat.decompose()
+            last = x
+            if l == len(features) - 1 and self.num_feature_levels > len(features):
+                x, last = HF.fanout(x, 2)        # C5 also feeds the extra stride-2 level
             conv = self.input_proj[l][0]
             src = HF.conv_bn_act(x, conv.weight, None, conv.bias, conv.stride, conv.padding, relu=False)
             if self.patch_size != 1:
-                mask = _nearest_mask(mask, src.shape[1], src.shape[2])
+                mask = level_mask(mask, src)
             srcs.append(src); masks.append(mask)
-            last = x
         for l in range(len(features), self.num_feature_levels):
             conv = self.input_proj[l][0]
             inp = last if l == len(features) else srcs[-1]
             src = HF.conv_bn_act(inp, conv.weight, None, conv.bias, conv.stride, conv.padding, relu=False)
-            masks.append(_nearest_mask(samples.mask, src.shape[1], src.shape[2]))
+            masks.append(level_mask(samples.mask, src))
             srcs.append(src)
         gammas = [p[1].weight for p in self.input_proj]
         betas = [p[1].bias for p in self.input_proj]

@@ -28,11 +28,27 @@ class NestedTensor(object):
         return str(self.tensors)
 
 
+_ZERO_MASKS = {}
+
+
+def cached_zero_mask(n, h, w, device, dtype=torch.bool):
+    """All-False (n, h, w) padding mask, one persistent tensor per geometry: a batch tensor of equally sized images has no
+    padding at any pyramid level, so the per-step mask resampling of the reference (backbone.py:94-97, roomformer_v2.py:
+    192-199: F.interpolate of an all-False mask) is a constant.  Read-only by convention."""
+    key = (int(n), int(h), int(w), str(device), dtype)
+    m = _ZERO_MASKS.get(key)
+    if m is None:
+        m = _ZERO_MASKS[key] = torch.zeros(n, h, w, dtype=dtype, device=device)
+    return m
+
+
 def nested_tensor_from_tensor_list(tensor_list):
     """Pad a list (or batch tensor) of CHW images to a common size; mask is True on padded pixels."""
     if isinstance(tensor_list, Tensor) and tensor_list.ndim == 4:
         b, c, h, w = tensor_list.shape
-        return NestedTensor(tensor_list, torch.zeros((b, h, w), dtype=torch.bool, device=tensor_list.device))
+        nt = NestedTensor(tensor_list, cached_zero_mask(b, h, w, tensor_list.device))
+        nt.no_padding = True
+        return nt
     if tensor_list[0].ndim != 3:
         raise ValueError("not supported")
     sizes = [list(img.shape) for img in tensor_list]

@@ -173,6 +173,35 @@ def test_conv_fwd_dgrad_wgrad(N, H, W, C, O, k, stride, pad):
     close(dw.view(O, k, k, C).permute(0, 3, 1, 2), w.grad, tol=2e-4, name="conv wgrad")
 
 
+@pytest.mark.parametrize("N,H,W,C,O,k,stride,pad,res", [(2, 8, 8, 512, 512, 3, 1, 1, False), (2, 8, 8, 2048, 256, 3, 2, 1, False),
+                                                       (8, 4, 4, 2048, 512, 1, 1, 0, True)])
+def test_conv_node_k_split_path(N, H, W, C, O, k, stride, pad, res):
+    """HF.conv_bn_act in grad mode takes the atomic k-split for few-tile / deep-contraction layers (zero fill, bias with split 0,
+    FrozenBN / ReLU / shortcut in a separate in-place pass; dgrad k-split too): same values as the single-pass launch that
+    inference uses, and the same gradients as torch (ref backbone.py:28-35 FrozenBatchNorm2d folding, torchvision Bottleneck)."""
+    from cape_amd.hip import functional as HF
+    x, w, geom, OH, OW = _conv_case(N, H, W, C, O, k, stride, pad)
+    sc, sh = rnd(O, seed=7).abs() + 0.5, rnd(O, seed=8)
+    r = rnd(N, O, OH, OW, seed=10) if res else None
+    x.requires_grad_(True); w.requires_grad_(True)
+    pre = F.conv2d(x, w, stride=stride, padding=pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    z_ref = F.relu(pre + r if res else pre)
+    g = rnd(*z_ref.shape, seed=9)
+    z_ref.backward(g)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    wn = torch.nn.Parameter(w.detach().to(DEV).contiguous(memory_format=torch.channels_last))
+    rn = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
+    with torch.no_grad():
+        z_single = HF.conv_bn_act(xn, wn, sc.to(DEV), sh.to(DEV), stride=stride, pad=pad, relu=True, residual=rn)
+    z = HF.conv_bn_act(xn, wn, sc.to(DEV), sh.to(DEV), stride=stride, pad=pad, relu=True, residual=rn)
+    assert ops.pick_split_k(N * OH * OW, O, k * k * C) >= 4          # the case does take the k-split
+    close(z.permute(0, 3, 1, 2), z_ref, name="conv node fwd (k-split)")
+    close(z, z_single, tol=2e-5, name="k-split vs single pass")
+    z.backward(g.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close(xn.grad.permute(0, 3, 1, 2), x.grad, tol=2e-4, name="conv node dgrad")
+    close(wn.grad, w.grad, tol=2e-4, name="conv node wgrad")
+
+
 # ---- fragment-packed weights of the register-stationary kernel (cape_pack_weights, ops.PackedWeights) ----
 @pytest.mark.parametrize("M,N,K,bm", [(5000, 256, 256, 0), (700, 384, 256, 1), (6400, 1024, 256, 0), (333, 100, 128, 1), (4097, 64, 64, 0),
                                       (6400, 70, 256, 0), (400, 70, 256, 0), (129, 33, 64, 1)])

@@ -20,6 +20,10 @@ SHAPES = [  # (M, N, K, a_mode, b_mode, split_k)
     (131072, 256, 64, 0, 0, 1), (32768, 512, 128, 0, 0, 1), (43520, 256, 128, 0, 1, 1), (43520, 128, 256, 0, 0, 1),
     (8192, 1024, 256, 0, 0, 1), (2176, 256, 256, 0, 0, 1),
 ]
+if os.environ.get("GEMM_BENCH_WGRAD"):          # k-split sweep of the weight-gradient shapes (pair with CAPE_GEMM_TILE=64|128)
+    SHAPES = [(m, n, k, 1, 1, sk) for (m, n, k) in [(256, 256, 43520), (1024, 256, 43520), (256, 1024, 43520), (128, 256, 43520),
+                                                     (256, 256, 6400), (1024, 256, 6400), (256, 1024, 6400), (256, 256, 544)]
+              for sk in (1, 4, 8, 16, 24, 32, 64, 128) if k // sk >= 128]
 if os.environ.get("GEMM_BENCH_RS_ONLY"):
     SHAPES = [s for s in SHAPES if s[3] == 0 and s[5] == 1 and s[2] in (64, 128, 256)]
 
