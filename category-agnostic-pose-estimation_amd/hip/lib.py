@@ -78,6 +78,34 @@ class DecodeTailDesc(ctypes.Structure):
     ]
 
 
+DECODE_MAX_LAYERS = 8
+
+
+class DecodeLayerDesc(ctypes.Structure):
+    """field-for-field `cape_decode_layer_desc` (include/cape_hip.h)"""
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "b_qkv", "w_qin", "k_cache", "v_cache", "w_o", "b_o", "ln2_g", "ln2_b",
+        "w_sq", "b_sq", "sup_k", "sup_v", "sup_mask", "w_so", "b_so", "lns_g", "lns_b",
+        "w_off", "b_off", "value", "w_mo", "b_mo", "ln1_g", "ln1_b",
+        "w1", "b1", "w2", "b2", "ln3_g", "ln3_b", "m1w", "m1b", "m2w", "m2b", "m3w", "m3b")]
+
+
+class DecodeStepDesc(ctypes.Structure):
+    """field-for-field `cape_decode_step_desc`"""
+    _fields_ = [
+        ("N", c_int), ("n_layers", c_int), ("step", c_int), ("T", c_int), ("P", c_int), ("S", c_int), ("L", c_int),
+        ("n_points", c_int), ("ncls", c_int), ("ffn_dim", c_int),
+        ("shapes", c_int * 8), ("level_start", c_int * 4),
+        ("emb", c_void_p), ("qpos0", c_void_p), ("refin0", c_void_p), ("ref0", c_void_p), ("vr", c_void_p), ("dim_t", c_void_p),
+        ("class_w", c_void_p), ("class_b", c_void_p),
+        ("pos_w", c_void_p), ("pos_b", c_void_p), ("pos_gamma", c_void_p), ("pos_beta", c_void_p),
+        ("out_logits", c_void_p), ("ld_logits", c_longlong),
+        ("out_coords", c_void_p), ("ld_coords", c_longlong),
+        ("out_hs", c_void_p), ("ld_hs", c_longlong),
+        ("layers", DecodeLayerDesc * DECODE_MAX_LAYERS),
+    ]
+
+
 P, I, LL, F, U32 = c_void_p, c_int, c_longlong, c_float, c_uint32
 _SIGS = {
     "cape_rng_advance": [P, P],
@@ -132,6 +160,7 @@ _SIGS = {
     "cape_decode_advance": [P, LL, P, LL, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P, P],
     "cape_decode_linear": [POINTER(DecodeLinearDesc), P],
     "cape_decode_tail": [POINTER(DecodeTailDesc), P],
+    "cape_decode_step": [POINTER(DecodeStepDesc), P],
 }
 EXPORTS = ["cape_last_error", "cape_abi_version", "cape_groupnorm_workspace_bytes", "cape_packed_weight_bytes"] + list(_SIGS)
 _lib.cape_packed_weight_bytes.argtypes = [I, I]

@@ -886,6 +886,77 @@ def decode_tail(P4, ln3, mlp, ref, ref_out, dim_t_, vr=None, cls_head=None, cls_
     lib.call("cape_decode_tail", ctypes.byref(d), _stream())
 
 
+class DecodeStepPlan:
+    """Persistent descriptor of cape_decode_step (csrc/decode_fused.hip): every pointer that does not change from step to
+    step is written once; `launch(step, ...)` fills in the step number, the step's table rows and output slots and launches.
+    Keeps the tensors it points to alive."""
+
+    def __init__(self, N, T, geo, n_points, ffn_dim, emb, vr, dim_t_, class_head, pos_trans, layers):
+        """layers: list of dicts with the field names of cape_decode_layer_desc -> tensors (sup_mask may be None)."""
+        d = lib.DecodeStepDesc()
+        self.keep = [emb, vr, dim_t_, class_head, pos_trans, layers]
+        assert 1 <= len(layers) <= lib.DECODE_MAX_LAYERS
+        _rows(emb, "decode_step.emb", 256); _chk(vr, "decode_step.vr"); _chk(dim_t_, "decode_step.dim_t")
+        assert emb.shape == (N, 256) and vr.numel() == N * geo.L * 2 and dim_t_.numel() == 128
+        d.N, d.n_layers, d.T, d.S, d.L, d.n_points, d.ffn_dim = N, len(layers), T, geo.S, geo.L, n_points, ffn_dim
+        for l, (h, w) in enumerate(geo.shapes):
+            d.shapes[2 * l], d.shapes[2 * l + 1] = h, w
+            d.level_start[l] = geo.starts[l]
+        d.emb, d.vr, d.dim_t = emb.data_ptr(), vr.data_ptr(), dim_t_.data_ptr()
+        Wc, bc = class_head
+        _chk(Wc, "decode_step.class_w"); _chk(bc, "decode_step.class_b")
+        assert Wc.shape[1] == 256 and bc.numel() == Wc.shape[0]
+        d.class_w, d.class_b, d.ncls = Wc.data_ptr(), bc.data_ptr(), Wc.shape[0]
+        Wp, bp, gp, bpn = pos_trans
+        for t_, shp in ((Wp, (256, 256)), (bp, (256,)), (gp, (256,)), (bpn, (256,))):
+            _chk(t_, "decode_step.pos_trans"); assert tuple(t_.shape) == shp
+        d.pos_w, d.pos_b, d.pos_gamma, d.pos_beta = Wp.data_ptr(), bp.data_ptr(), gp.data_ptr(), bpn.data_ptr()
+        P = None
+        shapes = {"w_qkv": (768, 256), "b_qkv": (768,), "w_qin": (256, 256), "k_cache": (N, T, 256), "v_cache": (N, T, 256),
+                  "w_o": (256, 256), "b_o": (256,), "ln2_g": (256,), "ln2_b": (256,), "w_sq": (256, 256), "b_sq": (256,),
+                  "w_so": (256, 256), "b_so": (256,), "lns_g": (256,), "lns_b": (256,), "w_off": (384, 256), "b_off": (384,),
+                  "value": (N, geo.S, 256), "w_mo": (256, 256), "b_mo": (256,), "ln1_g": (256,), "ln1_b": (256,),
+                  "w1": (ffn_dim, 256), "b1": (ffn_dim,), "w2": (256, ffn_dim), "b2": (256,), "ln3_g": (256,), "ln3_b": (256,),
+                  "m1w": (256, 256), "m1b": (256,), "m2w": (256, 256), "m2b": (256,), "m3w": (2, 256), "m3b": (2,)}
+        for l, lay in enumerate(layers):
+            ld = d.layers[l]
+            for name, shp in shapes.items():
+                t_ = lay[name]
+                _chk(t_, f"decode_step.layers[{l}].{name}")
+                assert tuple(t_.shape) == shp, (name, tuple(t_.shape), shp)
+                setattr(ld, name, t_.data_ptr())
+            for name in ("sup_k", "sup_v"):
+                t_ = lay[name]
+                _chk(t_, f"decode_step.layers[{l}].{name}")
+                assert t_.ndim == 3 and t_.shape[0] == N and t_.shape[2] == 256 and (P is None or t_.shape[1] == P)
+                P = t_.shape[1]
+                setattr(ld, name, t_.data_ptr())
+            m = lay.get("sup_mask")
+            if m is not None:
+                _chk(m, "decode_step.sup_mask", dtype=torch.uint8); assert tuple(m.shape) == (N, P)
+                ld.sup_mask = m.data_ptr()
+        d.P = P
+        self.d, self.N, self.T, self.L = d, N, T, geo.L
+
+    def launch(self, step, qpos0, refin0, ref0, out_logits, out_coords, out_hs):
+        """qpos0 (256,), refin0 (N, L, 2), ref0 (N, 2): layer-0 tables of this step; out_* row views (N, ncls) / (N, 2) / (N, 256)."""
+        d, N = self.d, self.N
+        assert 0 <= step < self.T
+        _chk(qpos0, "decode_step.qpos0"); _chk(refin0, "decode_step.refin0"); _chk(ref0, "decode_step.ref0")
+        assert qpos0.numel() == 256 and refin0.numel() == N * self.L * 2 and ref0.numel() == N * 2
+        for t_, w in ((out_logits, d.ncls), (out_coords, 2), (out_hs, 256)):
+            if not t_.is_cuda or t_.dtype != _F32 or t_.shape != (N, w) or t_.stride(1) != 1:
+                raise ValueError("decode_step: output slots must be (N, width) fp32 row views on the GPU")
+            if _avail(t_) < (N - 1) * t_.stride(0) + w:
+                raise ValueError("decode_step: output slot exceeds its storage")
+        d.step = step
+        d.qpos0, d.refin0, d.ref0 = qpos0.data_ptr(), refin0.data_ptr(), ref0.data_ptr()
+        d.out_logits, d.ld_logits = out_logits.data_ptr(), out_logits.stride(0)
+        d.out_coords, d.ld_coords = out_coords.data_ptr(), out_coords.stride(0)
+        d.out_hs, d.ld_hs = out_hs.data_ptr(), out_hs.stride(0)
+        lib.call("cape_decode_step", ctypes.byref(d), _stream())
+
+
 def decode_advance(cls_slot, reg_slot, unfinished_i32, tok_i64, delta, step, N, num_bins, min_len, eos, sep, pad, table=None,
                    embed_out=None, alive_out=None):
     """cls_slot (N, 3) / reg_slot (N, 2) row views (e.g. out_logits[:, i]); see cape_decode_advance."""

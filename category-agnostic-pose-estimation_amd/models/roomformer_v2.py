@@ -164,6 +164,27 @@ class RoomFormerV2(nn.Module):
         out["_stack_logits"], out["_stack_coords"] = inter_classes, inter_references
         return out
 
+    def _decode_plan(self, dec, dw, caches, emb, vr, geo, N):
+        """Descriptor of the whole-step decode kernel: the pointers of every decoder weight, cache and table (ops.DecodeStepPlan)."""
+        layers = []
+        for l, (layer, w, c) in enumerate(zip(dec.layers, dw, caches)):
+            sa, ca, m = layer.self_attn, layer.support_attn, layer.cross_attn
+            mlp = dec.coords_embed[l].layers
+            layers.append({
+                "w_qkv": w["w_qkv"], "b_qkv": sa.in_proj_bias, "w_qin": sa.in_proj_weight[:256], "k_cache": c["k"], "v_cache": c["v"],
+                "w_o": sa.out_proj.weight, "b_o": sa.out_proj.bias, "ln2_g": layer.norm2.weight, "ln2_b": layer.norm2.bias,
+                "w_sq": ca.in_proj_weight[:256], "b_sq": ca.in_proj_bias[:256], "sup_k": c["sup_k"], "sup_v": c["sup_v"],
+                "sup_mask": c["sup_kpm"], "w_so": ca.out_proj.weight, "b_so": ca.out_proj.bias,
+                "lns_g": layer.norm_support.weight, "lns_b": layer.norm_support.bias,
+                "w_off": w["w_off"], "b_off": w["b_off"], "value": c["value"], "w_mo": m.output_proj.weight, "b_mo": m.output_proj.bias,
+                "ln1_g": layer.norm1.weight, "ln1_b": layer.norm1.bias, "w1": layer.linear1.weight, "b1": layer.linear1.bias,
+                "w2": layer.linear2.weight, "b2": layer.linear2.bias, "ln3_g": layer.norm3.weight, "ln3_b": layer.norm3.bias,
+                "m1w": mlp[0].weight, "m1b": mlp[0].bias, "m2w": mlp[1].weight, "m2b": mlp[1].bias, "m3w": mlp[2].weight, "m3b": mlp[2].bias})
+        ce = dec.class_embed[len(dec.layers) - 1]
+        return ops.DecodeStepPlan(N, self.seq_len, geo, dec.layers[0].cross_attn.n_points, dec.layers[0].linear1.weight.shape[0], emb, vr,
+                                  ops.dim_t(emb.device), (ce.weight, ce.bias),
+                                  (dec.pos_trans.weight, dec.pos_trans.bias, dec.pos_trans_norm.weight, dec.pos_trans_norm.bias), layers)
+
     # ---- KV-cached autoregressive inference -------------------------------------------------------
     @torch.no_grad()
     def forward_inference(self, samples, use_cache=True, support_graphs=None, support_mask=None, sync_every=8,
@@ -185,7 +206,7 @@ class RoomFormerV2(nn.Module):
             graph = os.environ.get("CAPE_DECODE_GRAPH", "1") == "1"
         graph = graph and teacher_stream is None
         # fused step (csrc/decode_step.hip): ~75 launches instead of ~190; CAPE_DECODE_FUSED=0 keeps the per-op step for A/B
-        fused = os.environ.get("CAPE_DECODE_FUSED", "1") == "1" and memory_rows_ok(samples)
+        fused = os.environ.get("CAPE_DECODE_FUSED", "1") == "1"
         enc = self._encode_images(samples)
         dec = self.transformer.decoder
         geo, vr, memory = enc["geo"], enc["valid_ratios"], enc["memory"]
@@ -198,8 +219,15 @@ class RoomFormerV2(nn.Module):
         P = support.shape[1] if support is not None else 0
 
         # ---- state buffers (static per geometry when graphs are used) ----
-        fused = fused and N <= 64
-        key = (N, tuple(geo.shapes), P, smask is not None, max_len, str(dev), ops.get_gemm_precision(), fused)
+        # whole-step kernel (csrc/decode_fused.hip, one block per image, ONE launch per step): needs the CAPE layer shape
+        # (support attention in every layer, 4 levels x 4 points, dim_feedforward 1024); CAPE_DECODE_MEGA=0 keeps the
+        # launch-per-stage step for A/B
+        m0 = dec.layers[0].cross_attn
+        mega = (fused and os.environ.get("CAPE_DECODE_MEGA", "1") == "1" and P > 0 and geo.L * m0.n_points == 16 and
+                dec.layers[0].linear1.weight.shape[0] == 1024 and self.seq_len <= 1024 and P <= 1024 and geo.S < 65535 and
+                len(dec.layers) <= 8 and self.num_classes <= 8)
+        fused = fused and (N <= 64 or mega)
+        key = (N, tuple(geo.shapes), P, smask is not None, max_len, str(dev), ops.get_gemm_precision(), fused, mega)
         st = self._decode_states.get(key) if graph else None
         fresh = st is None
         if fresh:
@@ -285,11 +313,21 @@ class RoomFormerV2(nn.Module):
             alive_i32 = st["alive_i32"]
             alive_i32.zero_()
 
+            plan = None
+            if mega:
+                pkey = (sentinel, id(dw))
+                if st.get("plan_key") != pkey:
+                    st["plan"], st["plan_key"] = self._decode_plan(dec, dw, caches, wsb["emb"], vr_s, geo, N), pkey
+                plan = st["plan"]
+
             def step_body(i, toks_i, deltas_i):
                 if toks_i is not toks:                       # teacher forcing: the step's input tokens come from the stream
                     ops.token_embed_fwd_into(dec.token_embed.weight, toks_i, deltas_i, wsb["emb"])
-                decode_step_fused(dec, dw, wsb, caches, geo, vr_s, i, st["qpos0"][i], st["refin0"][i], st["ref0"][i], out_logits,
-                                  out_coords, out_hs)
+                if plan is not None:
+                    plan.launch(i, st["qpos0"][i], st["refin0"][i], st["ref0"][i], out_logits[:, i], out_coords[:, i], out_hs[:, i])
+                else:
+                    decode_step_fused(dec, dw, wsb, caches, geo, vr_s, i, st["qpos0"][i], st["refin0"][i], st["ref0"][i], out_logits,
+                                      out_coords, out_hs)
                 if toks_i is toks:
                     ops.decode_advance(out_logits[:, i], out_coords[:, i], unfinished, toks, deltas, i, N, tok.num_bins, min_len,
                                        tok.eos, tok.sep, tok.pad, table=dec.token_embed.weight, embed_out=wsb["emb"],
@@ -337,7 +375,8 @@ class RoomFormerV2(nn.Module):
         # the state buffers are reused by the next call: hand out copies
         out = {"pred_logits": out_logits[:, :T].clone(), "pred_coords": out_coords[:, :T].clone(), "gen_out": None}
         if timing:
-            out["_timing"] = {"events": (ev_loop0, ev_loop1), "steps_run": i, "launch": "graph" if use_graphs else "eager", "fused": fused}
+            out["_timing"] = {"events": (ev_loop0, ev_loop1), "steps_run": i, "launch": "graph" if use_graphs else "eager", "fused": fused,
+                              "whole_step_kernel": bool(fused and mega)}
         if self.room_class_embed is not None:
             hs2 = out_hs[:, :T].contiguous()
             rl = torch.empty(N, T, self.room_class_embed.weight.shape[0], device=dev)
@@ -350,12 +389,6 @@ class RoomFormerV2(nn.Module):
     def _setup_caches(self, max_bs, max_src_len):
         self.transformer._setup_caches(max_bs, self.seq_len, max_src_len, self.transformer.d_model, self.transformer.nhead,
                                        self.transformer.level_embed.dtype, device=self.transformer.level_embed.device)
-
-
-def memory_rows_ok(samples):
-    """The fused decode kernels take at most 64 token rows (images in flight) per launch."""
-    n = samples.tensors.shape[0] if isinstance(samples, NestedTensor) else (samples.shape[0] if isinstance(samples, torch.Tensor) else len(samples))
-    return n <= 64
 
 
 def _nearest_mask(mask, h, w):

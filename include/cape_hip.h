@@ -160,6 +160,59 @@ typedef struct {
 int cape_decode_tail(const cape_decode_tail_desc* d, cape_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * cape_decode_step: ONE launch for a whole cached decode step -- every decoder layer, for one query token per image
+ * (one 512-thread block per image; nothing in a step couples two images, so the chain of ~20 dependent matrix-vector
+ * stages per layer needs no grid-level synchronisation; weights stream through L2 into each block with the next stage's
+ * block always requested ahead).  Replaces the per-stage launches of cape_decode_linear / cape_attn_fwd / cape_msda_fwd /
+ * cape_decode_tail for one step of TransformerDecoder.forward (deformable_transformer_v2.py:1024-1131) with
+ * TransformerDecoderLayer v1 (:320-370), as driven by RoomFormerV2.forward_inference (roomformer_v2.py:481-598):
+ *   per layer l:  q|k|v = x W_qkv^T + b (folded attn_{q,k,v} . in_proj), q += query_pos W_qin^T; k, v -> row `step` of the
+ *   layer's cache; single-query self-attention over rows 0..step (8 heads x 32); out_proj + residual, norm2; [support
+ *   cross-attention over P cached keys with key-padding mask, out_proj + residual, norm_support]; sampling_offsets |
+ *   attention_weights of (t + query_pos); softmax over L*n_points = 16 logits per head + bilinear gather from the cached
+ *   value projection (N, S, 256); output_proj + residual, norm1; linear1 + ReLU, linear2 + residual; norm3; coords MLP
+ *   (256-256-256-2) + refinement sigmoid(delta + logit(ref)); [last layer: class head, hidden state] / [else: next layer's
+ *   query position embedding LN(pos_trans(sine(ref'))) and level-scaled reference points ref' * valid_ratio].
+ * All matrices row-major [out][in] fp32, 16-byte aligned.  Model width 256, 8 heads, L * n_points == 16, ffn_dim a multiple
+ * of 256 (<= 1024), S < 65535, cache rows T <= 1024, P <= 1024.  w_sq == NULL: no support attention in that layer.
+ * ---------------------------------------------------------------------------------------------- */
+#define CAPE_DECODE_MAX_LAYERS 8
+typedef struct {
+  const float *w_qkv, *b_qkv;            /* (768, 256) folded projection, (768,) in_proj_bias */
+  const float* w_qin;                    /* (256, 256) in_proj_weight[:256]: carries `+ query_pos` of the query */
+  float *k_cache, *v_cache;              /* (N, T, 256) */
+  const float *w_o, *b_o, *ln2_g, *ln2_b;
+  const float *w_sq, *b_sq;              /* support attention: query projection (in_proj rows 0..255) or NULL */
+  const float *sup_k, *sup_v;            /* (N, P, 256) projected support keys / values */
+  const unsigned char* sup_mask;         /* (N, P) nonzero = padded key, or NULL */
+  const float *w_so, *b_so, *lns_g, *lns_b;
+  const float *w_off, *b_off;            /* (384, 256) sampling_offsets | attention_weights, (384,) */
+  const float* value;                    /* (N, S, 256) cached value projection of the image memory */
+  const float *w_mo, *b_mo, *ln1_g, *ln1_b;
+  const float *w1, *b1, *w2, *b2;        /* (F, 256), (F,), (256, F), (256,) */
+  const float *ln3_g, *ln3_b;
+  const float *m1w, *m1b, *m2w, *m2b, *m3w, *m3b;   /* coords MLP of this layer: (256,256) (256,256) (2,256) */
+} cape_decode_layer_desc;
+typedef struct {
+  int N, n_layers, step, T, P, S, L, n_points, ncls, ffn_dim;
+  int shapes[8];                         /* (H_l, W_l) per level */
+  int level_start[4];
+  const float* emb;                      /* (N, 256) embedding of the step's input tokens */
+  const float* qpos0;                    /* (256,) layer-0 query position embedding of this step (same for all images) */
+  const float* refin0;                   /* (N, L, 2) layer-0 level-scaled reference points */
+  const float* ref0;                     /* (N, 2) layer-0 reference points */
+  const float* vr;                       /* (N, L, 2) valid ratios */
+  const float* dim_t;                    /* (128,) sine periods */
+  const float *class_w, *class_b;        /* (ncls, 256), (ncls,): class head of the last layer */
+  const float *pos_w, *pos_b, *pos_gamma, *pos_beta;   /* pos_trans + pos_trans_norm (shared by the layers) */
+  float* out_logits; long long ld_logits;   /* row n of this step's slot: out_logits + n * ld_logits, ncls values */
+  float* out_coords; long long ld_coords;   /* 2 values */
+  float* out_hs; long long ld_hs;           /* 256 values: last layer's normalised hidden state */
+  cape_decode_layer_desc layers[CAPE_DECODE_MAX_LAYERS];
+} cape_decode_step_desc;
+int cape_decode_step(const cape_decode_step_desc* d, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * out = LayerNorm(x + dropout(y)) * gamma + beta over rows of C (C <= 1024, C % 4 == 0), eps 1e-5.
  * y may be NULL (plain LayerNorm).  Saves mean/rstd (per row) for backward.  If pos != NULL also writes
  * out_pos = out + pos (the `with_pos_embed` add, deformable_transformer.py:197).

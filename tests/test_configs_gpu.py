@@ -99,6 +99,38 @@ def test_cfg5_512_patch2_5shot_decode(golden_dir):
     assert torch.equal(p["sequences"].cpu()[:, :n][big[:, :n]], ref_seq[:, :n][big[:, :n]])
 
 
+@pytest.mark.parametrize("images", [2, 5])
+def test_whole_step_decode_kernel_matches_stage_kernels(images, monkeypatch):
+    """cape_decode_step (one launch per step, one block per image) against the launch-per-stage step on the configs[4] model:
+    same logits / coordinates / hidden states to fp32 rounding of the differently ordered sums, same token streams, and
+    eager == captured == replayed bit for bit.  5 images: an odd batch that is not the one the fixtures were made with."""
+    args, tok, model, crit = build_product(extra=("--image_size", "512"), proc_sd=proc_sd_512())
+    model.eval()
+    tok.seq_len = 24
+    b = cfg5_episode_batch()
+    rep = (images + 1) // 2
+    imgs = b["query_images"].repeat(rep, 1, 1, 1)[:images].cuda()
+    imgs = imgs + 0.05 * torch.randn(imgs.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    sc, sm = b["support_coords"].repeat(rep, 1, 1)[:images].cuda(), b["support_masks"].repeat(rep, 1)[:images].cuda()
+    sk = (b["support_skeletons"] * rep)[:images]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CAPE_DECODE_MEGA", mode)
+        with torch.no_grad():
+            outs[mode] = model.forward_inference(samples=imgs, support_coords=sc, support_mask=sm, skeleton_edges=sk, graph=False)
+    a, w = outs["0"], outs["1"]
+    n = min(a["logits"].shape[1], w["logits"].shape[1])
+    assert n >= 6
+    assert (a["logits"][:, :6] - w["logits"][:, :6]).abs().max() < 2e-5 and (a["coordinates"][:, :6] - w["coordinates"][:, :6]).abs().max() < 2e-6
+    top2 = a["logits"][:, :n].sort(-1).values
+    clear = (top2[..., 2] - top2[..., 1]) > 1e-3
+    assert torch.equal(a["sequences"][:, :n][clear], w["sequences"][:, :n][clear])
+    with torch.no_grad():
+        for _ in range(2):
+            g = model.forward_inference(samples=imgs, support_coords=sc, support_mask=sm, skeleton_edges=sk, graph=True)
+            assert torch.equal(g["logits"], w["logits"]) and torch.equal(g["coordinates"], w["coordinates"])
+
+
 def test_evaluate_cape_with_criterion(golden_dir):
     """a17: `evaluate_cape` end to end on the device (pad / trim to the target length -> HIP criterion -> PCK) against the
     reference's stats for the crafted predictions of eval_glue.npz."""
