@@ -400,8 +400,12 @@ def main():
         try:
             d1 = decode_benchmark(device, episodes=1)                     # configs[4] as stated: one 5-shot episode in flight
             d16 = decode_benchmark(device, episodes=16)                   # the same step with 32 images in flight
-            decode = dict(d1, batched_32_images={k: d16[k] for k in ("images", "steps", "us_per_step_eager", "us_per_step_graph",
-                                                                   "tokens_per_s", "images_per_s_200_steps", "roofline")})
+            keys = ("images", "steps", "us_per_step_eager", "us_per_step_graph", "tokens_per_s", "images_per_s_200_steps", "roofline",
+                    "cu_stream", "whole_step_kernel", "launches_per_step")
+            decode = dict(d1, batched_32_images={k: d16[k] for k in keys})
+            if d16.get("whole_step_kernel"):                              # one block per image: the step time does not grow with the batch
+                d64 = decode_benchmark(device, episodes=64, reps=2)
+                decode["batched_128_images"] = {k: d64[k] for k in keys}
             log(f"decode: {d1['us_per_step_graph']} us/step (1 episode, graphs), {d16['us_per_step_graph']} us/step at 32 images")
             pck = pck_check(device)
             log(f"pck_check: {pck}")

@@ -53,9 +53,11 @@ def decode_benchmark(device, episodes=1, image_size=512, keypoints=68, shots=5, 
         out = model.forward_inference(im, sc, sm, skeleton_edges=sk, graph=graph, timing=True)
         torch.cuda.synchronize()
         tm = out["_timing"]
+        whole[0] = bool(tm.get("whole_step_kernel"))
         return tm["events"][0].elapsed_time(tm["events"][1]), tm["steps_run"], tm["launch"], tm["fused"]
 
     res = {}
+    whole = [False]
     with torch.no_grad():
         run(False)                                              # warm-up (allocator, lazily set kernel attributes)
         ms, steps, _, fused = min(run(False) for _ in range(reps))
@@ -68,10 +70,14 @@ def decode_benchmark(device, episodes=1, image_size=512, keypoints=68, shots=5, 
     return {"workload": f"{shots}-shot KV-cached decode, {image_size}x{image_size}, {keypoints} support keypoints, "
                         f"{episodes} episode(s) x {queries} queries = {N} images in flight",
             "images": N, "image_size": image_size, "support_keypoints": keypoints, "shots": shots, "steps": res["graph"]["steps"],
-            "fused_step_kernels": bool(fused),
+            "fused_step_kernels": bool(fused), "whole_step_kernel": whole[0], "launches_per_step": 2 if whole[0] else (75 if fused else 190),
             "us_per_step_eager": round(res["eager"]["ms_per_step"] * 1e3, 1), "us_per_step_graph": round(res["graph"]["ms_per_step"] * 1e3, 1),
             "tokens_per_s": round(N / (best * 1e-3), 1), "images_per_s_200_steps": round(N / (best * 200 * 1e-3), 2),
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round(nbytes / (best * 1e-3) / 1e9, 2),
                          "frac": round(nbytes / (best * 1e-3) / 1e9 / 8000.0, 5), "algorithmic_bytes_per_step": nbytes,
-                         "note": "decoder weights streamed once per step for the whole batch (SURVEY 8d); the step is a chain of "
-                                 "dependent small products, so it is launch-latency bound, not bandwidth bound"}}
+                         "note": "decoder weights counted once per step for the whole batch (SURVEY 8d); the step is a chain of "
+                                 "dependent small products, i.e. latency bound, not HBM bound"},
+            # the whole-step kernel streams every decoder weight through EACH image's compute unit (one block per image):
+            # its own bound is what one CU can ingest from L2 / Infinity Cache (tools/lab/cu_ingest.hip: 107-120 GB/s)
+            "cu_stream": {"bound": "per-CU ingest", "unit": "GB/s", "peak": 110.0, "achieved": round(nbytes / (best * 1e-3) / 1e9, 2),
+                          "frac": round(nbytes / (best * 1e-3) / 1e9 / 110.0, 4)} if whole[0] else None}

@@ -36,3 +36,19 @@ def test_null_descriptor_is_rejected_without_gpu():
     import ctypes
     rc = lib.raw().cape_gemm_f32(None, None)
     assert rc != 0 and "null" in lib.last_error()
+
+
+def test_decode_step_descriptor_checks_without_gpu():
+    """cape_decode_step validates its descriptor on the host before anything touches a device: null descriptor, a step outside the
+    cache, a layer count beyond the table, a sampling layout other than 4 levels x 4 points."""
+    import ctypes
+    raw = lib.raw()
+    assert raw.cape_decode_step(None, None) != 0 and "null" in lib.last_error()
+    d = lib.DecodeStepDesc()
+    d.N, d.n_layers, d.T, d.step, d.P, d.S, d.L, d.n_points, d.ncls, d.ffn_dim = 2, 6, 40, 40, 17, 100, 4, 4, 3, 1024
+    assert raw.cape_decode_step(ctypes.byref(d), None) != 0 and "step" in lib.last_error()
+    d.step, d.n_layers = 3, lib.DECODE_MAX_LAYERS + 1
+    assert raw.cape_decode_step(ctypes.byref(d), None) != 0 and "layers" in lib.last_error()
+    d.n_layers, d.n_points = 6, 2
+    assert raw.cape_decode_step(ctypes.byref(d), None) != 0 and "points" in lib.last_error()
+    assert ctypes.sizeof(lib.DecodeStepDesc) == 2600 and ctypes.sizeof(lib.DecodeLayerDesc) == 37 * 8
