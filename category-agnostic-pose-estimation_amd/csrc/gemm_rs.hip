@@ -96,10 +96,8 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
   uint64_t seed = 0, step = 0;
   if constexpr (EPI == 4) { seed = p.rng_state[0]; step = p.rng_state[1]; }
   // 32-bit element offsets from a wave-uniform row base (host-checked: every M * ld < 2^31)
-  const int ldc = (int)p.ldc, ldr = (int)p.ldr, ldm = (int)p.ldm;
+  const int ldc = (int)p.ldc;
   const unsigned lo_c = (unsigned)(4 * h * ldc + col);
-  const unsigned lo_r = (unsigned)(4 * h * ldr + col);
-  const unsigned lo_m = (unsigned)(4 * h * ldm + col);
 
   auto store_piece = [&](float4& v, int i, int buf) {          // one float4 of a unit: split + two 8-byte LDS stores
     unsigned short* Ph = lds + buf * 2 * G::PLANE + (st_row + RSTEP * i) * LD + 4 * st_kc;
@@ -189,9 +187,28 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
     const unsigned short* Al = Ah + G::PLANE;
     const bool full = (u + 1) * RS_UNIT <= p.M;
     constexpr int H1 = (NW == 8) ? 2 : 1;
+    // EPI 1..3: the extra operand (residual / gate source / old C) of a tile is requested before its first
+    // MFMA: left in the epilogue, its round trip sat between the last MFMA and the stores of every tile (the gated FFN
+    // dgrad ran 2x longer than the plain product of the same shape)
 #pragma unroll
     for (int hh = 0; hh < H1; ++hh) {
       const int half = (NW == 8) ? hh : wm;
+      float xv[16];
+      if constexpr (EPI >= 1 && EPI <= 3) {
+        if (col_ok) {
+          const int rb = u * RS_UNIT + 32 * half;
+          // (eligibility guarantees ldr == ldc / ldm == ldc: the operand shares the 32-bit lane offsets of the C stores, only
+          // its SGPR base differs -- with offsets of its own the 16 extra address registers spilled)
+          const float* xb = EPI == 1 ? p.residual : EPI == 2 ? p.mask_src : p.C;
+          const float* x0 = xb + (long long)rb * ldc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int roff = (i & 3) + 8 * (i >> 2);
+            if (full) xv[i] = x0[lo_c + (unsigned)(roff * ldc)];
+            else xv[i] = xb[(long long)min(rb + roff + 4 * h, p.M - 1) * ldc + col];   // ragged last unit: clamped rows, never stored
+          }
+        }
+      }
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -232,30 +249,15 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
           if (roff < rlim) c0[lo_c + (unsigned)(roff * ldc)] = v;
         }
       } else {
-        // one extra operand stream (residual / gate source / old C): unconditional loads from clamped rows, 8 at a time
-        const float* x0 = EPI == 1 ? p.residual + (long long)rb * ldr : EPI == 2 ? p.mask_src + (long long)rb * ldm : c0;
-        const int ldx = EPI == 1 ? ldr : EPI == 2 ? ldm : ldc;
-        const unsigned lo_x = EPI == 1 ? lo_r : EPI == 2 ? lo_m : lo_c;
-        // a ragged last unit clamps the absolute row (rows >= M are loaded from row M - 1 and never stored)
-        const float* xb = EPI == 1 ? p.residual : EPI == 2 ? p.mask_src : p.C;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          float xv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int i = 8 * g + e, roff = (i & 3) + 8 * (i >> 2);
-            if (full) xv[e] = x0[lo_x + (unsigned)(roff * ldx)];
-            else xv[e] = xb[(long long)min(rb + roff + 4 * h, p.M - 1) * ldx + col];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int i = 8 * g + e, roff = (i & 3) + 8 * (i >> 2);
-            float v = fmaf(acc[i], sc, bi);
-            if constexpr (EPI == 1) v = fmaxf(v + xv[e], floor_v);
-            if constexpr (EPI == 2) v = xv[e] != 0.f ? fmaxf(v, floor_v) * p.mask_scale : 0.f;
-            if constexpr (EPI == 3) v = fmaxf(v, floor_v) + xv[e];
-            if (roff < rlim) c0[lo_c + (unsigned)(roff * ldc)] = v;
-          }
+        for (int i = 0; i < 16; ++i) {
+          const int roff = (i & 3) + 8 * (i >> 2);
+          const float x = xv[i];
+          float v = fmaf(acc[i], sc, bi);
+          if constexpr (EPI == 1) v = fmaxf(v + x, floor_v);
+          if constexpr (EPI == 2) v = x != 0.f ? fmaxf(v, floor_v) * p.mask_scale : 0.f;
+          if constexpr (EPI == 3) v = fmaxf(v, floor_v) + x;
+          if (roff < rlim) c0[lo_c + (unsigned)(roff * ldc)] = v;
         }
       }
     }
@@ -362,8 +364,9 @@ bool cape_gemm_rs_eligible(const GemmP& p, int a_mode, int b_mode) {
   if (p.Bpack && !al16(p.Bpack)) return false;
   if (!p.Bpack && b_mode == 0 && (!al16(p.B) || p.ldb % 4 != 0)) return false;
   const long long lim = 1ll << 31;                                   // 32-bit lane offsets in the epilogue
-  if ((long long)p.M * p.ldc >= lim || (p.residual && (long long)p.M * p.ldr >= lim) || (p.mask_src && (long long)p.M * p.ldm >= lim))
-    return false;
+  if ((long long)p.M * p.ldc >= lim) return false;
+  if ((p.residual && p.ldr != p.ldc) || (p.mask_src && p.ldm != p.ldc)) return false;      // the epilogue operand shares C's offsets
+
   return true;
 }
 

@@ -94,6 +94,11 @@ def pick_split_k(M, N, K):
     """Enough tiles to fill 256 CUs about twice; each split keeps >= 8 k-tiles of 32."""
     if _NO_SPLIT_K:
         return 1
+    if M * N >= 256 * 1024 and K >= 32768:
+        # big outputs over a very deep contraction (the FFN weight gradients 1024 x 256 x 43520): the kernel takes 128 x 128
+        # tiles here, and two k-splits per CU beat one (profiles/r02_wgrad_sweep.txt: 101 us at split 32 vs 116-123 at 16)
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        return max(8, min(512 // t128, K // 1024) // 8 * 8)
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     ktiles = (K + 31) // 32
     want = max(1, 1024 // max(tiles, 1))

@@ -28,7 +28,30 @@ if os.environ.get("GEMM_BENCH_RS_ONLY"):
     SHAPES = [s for s in SHAPES if s[3] == 0 and s[5] == 1 and s[2] in (64, 128, 256)]
 
 
+def epilogue_sweep():
+    """Products with one extra epilogue operand (residual / ReLU-dropout gate from a saved activation / accumulate)."""
+    dev = "cuda"
+    for (M, N, K, bm) in [(43520, 1024, 256, 1), (43520, 256, 256, 0), (43520, 256, 256, 1), (6400, 1024, 256, 1), (6400, 256, 256, 0)]:
+        A = torch.randn(M, K, device=dev)
+        B = torch.nn.Parameter(torch.randn((N, K) if bm == 0 else (K, N), device=dev))
+        C = torch.zeros(M, N, device=dev)
+        X = torch.relu(torch.randn(M, N, device=dev))
+        for name, kw in (("plain", {}), ("residual", {"residual": X}), ("gate", {"mask_src": X, "mask_scale": 1.1}), ("accumulate", {"accumulate": True})):
+            for _ in range(3):
+                ops.gemm(A, B, C, M, N, K, b_mode=bm, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm(A, B, C, M, N, K, b_mode=bm, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"M={M:6d} N={N:5d} K={K:4d} bm={bm} {name:10s}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+
+
 def main():
+    if os.environ.get("GEMM_BENCH_EPI"):
+        return epilogue_sweep()
     dev = "cuda"
     for (M, N, K, am, bm, sk) in SHAPES:
         A = torch.randn((M, K) if am == 0 else (K, M), device=dev)
