@@ -556,6 +556,54 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP pin) {
   if (drop) { seed = p.rng_state[0]; step = p.rng_state[1]; }
   const bool atomic = p.split_k > 1;
   const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  // Interior tiles with at most one extra epilogue operand take a branch-free form: the row base of accumulator register r is
+  // wave-uniform (SGPR pointer arithmetic), the lane part is one 32-bit offset shared by the stores and by the operand
+  // (host-checked: ldr == ldc, ldm == ldc), and the operand's 16 values are requested before the first store.  The generic
+  // loop below (per-element conditions, 64-bit addresses) keeps the edge tiles, dropout and combined epilogues.
+  const int n_extra = (p.residual != nullptr) + (p.mask_src != nullptr) + (p.accumulate != 0) + (drop ? 1 : 0);
+  const bool same_ld = (!p.residual || p.ldr == p.ldc) && (!p.mask_src || p.ldm == p.ldc);
+  if (interior && !drop && n_extra <= 1 && same_ld && (long long)BM * p.ldc < (1ll << 30)) {
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_s = wave_s >> 1, wn_s = wave_s & 1;
+    const int ldc = (int)p.ldc;
+    const float floor_v = p.relu ? 0.f : -INFINITY;
+    const float* xb = p.residual ? p.residual : p.mask_src ? p.mask_src : (p.accumulate && !atomic) ? p.C : nullptr;
+    const int kind = atomic ? 1 : p.residual ? 2 : p.mask_src ? 3 : p.accumulate ? 4 : 0;     // block-uniform
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int colb = n0 + wn_s * WTN + j * 32;                                   // uniform
+        const long long base = (long long)(m0 + wm_s * WTM + i * 32) * ldc + colb;    // uniform
+        float* c0 = p.C + base;
+        const unsigned lo = (unsigned)(4 * lh * ldc + l31);
+        const float sc = p.scale ? p.scale[colb + l31] : 1.f;
+        const float bi = p.bias ? p.bias[colb + l31] : 0.f;
+        if (kind == 1) {
+          const float b0 = split == 0 ? bi : 0.f;                                  // the bias rides with the first k-split
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(c0 + (lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * ldc)), acc[i][j][r] + b0);
+        } else if (kind == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c0[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * ldc)] = fmaxf(fmaf(acc[i][j][r], sc, bi), floor_v);
+        } else {
+          const float* x0 = xb + base;
+          float xv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xv[r] = x0[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * ldc)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = fmaf(acc[i][j][r], sc, bi);
+            if (kind == 2) v = fmaxf(v + xv[r], floor_v);
+            else if (kind == 3) v = xv[r] != 0.f ? fmaxf(v, floor_v) * p.mask_scale : 0.f;
+            else v = fmaxf(v, floor_v) + xv[r];
+            c0[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * ldc)] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
 #pragma unroll
