@@ -368,15 +368,19 @@ class ConvFn(torch.autograd.Function):
         wp = _w_phys(weight)
         dx = dw = dshift = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(N, H, W, C, dtype=torch.float32, device=dy.device)
+            # `accum_dx` (set by BottleneckFn): a gradient of the same input that already exists (the shortcut branch's) --
+            # the data gradient is added into it by the accumulate epilogue instead of a separate summation pass
+            acc_dx = getattr(ctx, "accum_dx", None)
+            dx = acc_dx if acc_dx is not None else torch.empty(N, H, W, C, dtype=torch.float32, device=dy.device)
             if dense:
-                ops.gemm(dpre, wp, dx, M, C, O, a_mode=0, b_mode=1)
+                ops.gemm(dpre, wp, dx, M, C, O, a_mode=0, b_mode=1, accumulate=acc_dx is not None)
             else:
                 sk = ops.pick_split_k(N * H * W, C, KH * KW * O)
                 sk = sk if sk >= 4 else 1
-                if sk > 1:
+                if sk > 1 and acc_dx is None:
                     dx.zero_()
-                ops.gemm(dpre, wp, dx, N * H * W, C, KH * KW * O, a_mode=3, b_mode=2, conv=geom, split_k=sk, accumulate=sk > 1)
+                ops.gemm(dpre, wp, dx, N * H * W, C, KH * KW * O, a_mode=3, b_mode=2, conv=geom, split_k=sk,
+                         accumulate=sk > 1 or acc_dx is not None)
         wsink = _sink(ctx.w_ref)
         ssink = _sink(ctx.shift_ref) if (has_shift and ctx.needs_input_grad[3]) else None
         need_w = ctx.needs_input_grad[1]
@@ -421,6 +425,62 @@ def _relu_bwd_noscale(dy, y, relu, want_res):
 
 def _mask_only(dy, y, relu):
     return ops.relu_drop_bwd(dy, y, 1.0) if relu else dy
+
+
+class _PlainCtx:
+    """Stand-in for an autograd context when one Function runs several ConvFn stages itself."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+        self.accum_dx = None
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class BottleneckFn(torch.autograd.Function):
+    """torchvision Bottleneck v1.5 with FrozenBatchNorm2d (reference backbone.py:20-57 over torchvision.models.resnet50) as ONE
+    autograd node: conv1-bn-relu, conv2(3x3, stride)-bn-relu, [downsample conv-bn], conv3-bn + shortcut + relu.  The backward
+    runs the four ConvFn stages in order and lets conv1's data gradient accumulate into the shortcut's gradient (the block
+    input has two consumers; as separate nodes their gradients cost a summation pass over the largest tensors of the trunk),
+    and the host pays for one node instead of five."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, stride, allow_split):
+        nx = ctx.needs_input_grad[0]
+        c1 = _PlainCtx((nx, w1.requires_grad, False, False, False))
+        o1 = ConvFn.forward(c1, x, w1, s1, b1, None, 1, 0, True, allow_split)
+        c2 = _PlainCtx((True, w2.requires_grad, False, False, False))
+        o2 = ConvFn.forward(c2, o1, w2, s2, b2, None, stride, 1, True, allow_split)
+        cd, idt = None, x
+        if wd is not None:
+            cd = _PlainCtx((nx, wd.requires_grad, False, False, False))
+            idt = ConvFn.forward(cd, x, wd, sd, bd, None, stride, 0, False, allow_split)
+        c3 = _PlainCtx((True, w3.requires_grad, False, False, nx or wd is not None))
+        y = ConvFn.forward(c3, o2, w3, s3, b3, idt, 1, 0, True, allow_split)
+        ctx.sub = (c1, c2, c3, cd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c1, c2, c3, cd = ctx.sub
+        d2, dw3, _, _, dres = ConvFn.backward(c3, dy)[:5]
+        d1, dw2 = ConvFn.backward(c2, d2)[:2]
+        dwd = None
+        if cd is not None:
+            dxd, dwd = ConvFn.backward(cd, dres)[:2]
+            c1.accum_dx = dxd                       # None when the block input needs no gradient
+        else:
+            c1.accum_dx = dres if c1.needs_input_grad[0] else None
+        dx, dw1 = ConvFn.backward(c1, d1)[:2]
+        return (dx, dw1, dw2, dw3, dwd) + (None,) * 10
+
+
+def bottleneck(x, w1, w2, w3, wd, bn1, bn2, bn3, bnd, stride):
+    """bnK = (scale, shift) of the folded FrozenBatchNorm2d; wd / bnd = None without a projection shortcut."""
+    sd, bd = bnd if bnd is not None else (None, None)
+    return BottleneckFn.apply(x, w1, w2, w3, wd, bn1[0], bn1[1], bn2[0], bn2[1], bn3[0], bn3[1], sd, bd, int(stride), torch.is_grad_enabled())
 
 
 def conv_bn_act(x, weight, scale, shift, stride=1, pad=0, relu=False, residual=None):

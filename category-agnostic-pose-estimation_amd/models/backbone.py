@@ -79,17 +79,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        s1, b1 = self.bn1.folded()
-        s2, b2 = self.bn2.folded()
-        s3, b3 = self.bn3.folded()
-        x, idt = HF.fanout(x, 2)                  # two consumers: their gradients are summed by one cape_add_n_f32 pass
-        out = HF.conv_bn_act(x, self.conv1.weight, s1, b1, 1, 0, relu=True)
-        out = HF.conv_bn_act(out, self.conv2.weight, s2, b2, self.stride, 1, relu=True)
-        if self.downsample is not None:
-            sd, bd = self.downsample[1].folded()
-            idt = HF.conv_bn_act(idt, self.downsample[0].weight, sd, bd, self.stride, 0, relu=False)
-        # relu(bn3(conv3(out)) + identity) in one epilogue
-        return HF.conv_bn_act(out, self.conv3.weight, s3, b3, 1, 0, relu=True, residual=idt)
+        bnd = self.downsample[1].folded() if self.downsample is not None else None
+        wd = self.downsample[0].weight if self.downsample is not None else None
+        # one autograd node per block (HF.BottleneckFn): relu(bn3(conv3(...)) + shortcut) in one epilogue, and in the backward
+        # conv1's data gradient accumulates into the shortcut's gradient
+        return HF.bottleneck(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, wd, self.bn1.folded(), self.bn2.folded(),
+                             self.bn3.folded(), bnd, self.stride)
 
 
 class ResNet50Body(nn.Module):
