@@ -131,6 +131,28 @@ def test_whole_step_decode_kernel_matches_stage_kernels(images, monkeypatch):
             assert torch.equal(g["logits"], w["logits"]) and torch.equal(g["coordinates"], w["coordinates"])
 
 
+def test_whole_step_decode_kernel_beyond_64_images():
+    """One block per image: the whole-step kernel takes batches the launch-per-stage kernels (<= 64 rows) cannot.  66 images at
+    256x256; nothing couples two images, so the first five must decode exactly as when they are decoded alone."""
+    args, tok, model, crit = build_product()
+    model.eval()
+    tok.seq_len = 12
+    g = torch.Generator().manual_seed(11)
+    N = 66
+    imgs = torch.rand(N, 3, 256, 256, generator=g).cuda()
+    sc = torch.rand(N, 17, 2, generator=g).cuda()
+    sm = (torch.arange(17)[None, :] < torch.randint(4, 14, (N, 1), generator=g)).cuda()      # ragged visibility per image
+    sk = [[[0, 1], [1, 2], [2, 3]] for _ in range(N)]
+    with torch.no_grad():
+        big = model.forward_inference(samples=imgs, support_coords=sc, support_mask=sm, skeleton_edges=sk, graph=False)
+        small = model.forward_inference(samples=imgs[:5], support_coords=sc[:5], support_mask=sm[:5], skeleton_edges=sk[:5], graph=False)
+    n = min(big["logits"].shape[1], small["logits"].shape[1])
+    assert n >= 3 and big["logits"].shape[0] == N
+    assert (big["logits"][:5, :n] - small["logits"][:, :n]).abs().max() < 2e-5
+    assert (big["coordinates"][:5, :n] - small["coordinates"][:, :n]).abs().max() < 2e-6
+    assert torch.isfinite(big["logits"]).all()
+
+
 def test_evaluate_cape_with_criterion(golden_dir):
     """a17: `evaluate_cape` end to end on the device (pad / trim to the target length -> HIP criterion -> PCK) against the
     reference's stats for the crafted predictions of eval_glue.npz."""
