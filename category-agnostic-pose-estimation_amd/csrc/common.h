@@ -40,13 +40,32 @@ static inline uint32_t cape_drop_threshold(float p) {
   return (uint32_t)t;
 }
 
+// ---- wave-wide reductions on the VALU: DPP inside a 16-lane row (quad xor 1, xor 2, half-row mirror, row mirror), then
+// v_permlane16_swap / v_permlane32_swap across rows (new on gfx950).  The shuffle form (6 dependent ds_bpermute = LDS crossbar
+// round trips) put ~1 us of latency into every LayerNorm row and softmax; this one is ~12 VALU instructions.
+// The swaps are inline asm: `__builtin_amdgcn_permlane32_swap` on hipcc 7.2 adds result 0 to itself when both results feed
+// one add (tools/lab/permlane_probe2.hip).  All lanes end up with the result, like the shuffle butterflies they replace.
+template <int CTRL>
+__device__ __forceinline__ float cape_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void cape_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void cape_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += cape_dpp<0xB1>(v); v += cape_dpp<0x4E>(v); v += cape_dpp<0x141>(v); v += cape_dpp<0x140>(v);   // 16-lane row sums
+  float a = v, b = v;
+  cape_swap16(a, b);                                              // a = {r0, r0, r2, r2}, b = {r1, r1, r3, r3}
+  v = a + b;
+  a = v; b = v;
+  cape_swap32(a, b);                                              // a = {lo, lo}, b = {hi, hi}
+  return a + b;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, cape_dpp<0xB1>(v)); v = fmaxf(v, cape_dpp<0x4E>(v)); v = fmaxf(v, cape_dpp<0x141>(v)); v = fmaxf(v, cape_dpp<0x140>(v));
+  float a = v, b = v;
+  cape_swap16(a, b);
+  v = fmaxf(a, b);
+  a = v; b = v;
+  cape_swap32(a, b);
+  return fmaxf(a, b);
 }

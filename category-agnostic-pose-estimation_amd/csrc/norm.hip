@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict
 // backward.  Each block walks ROWS_PER_BLOCK rows (4 waves x 8 rows), keeps dgamma/dbeta partials of
 // its columns in registers, combines the 4 waves through LDS and issues one atomic per column.
 // ---------------------------------------------------------------------------------------------
-constexpr int LN_BWD_ROWS = 32;
+constexpr int LN_BWD_ROWS = 16;      // rows per block (4 waves x 4 rows): twice the blocks of the first version -- a wave's rows are a serial
+                                      // chain of load -> reduce -> store, more waves in flight hide more of it
 
 __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ d_out_pos,
                                                           const float* __restrict__ x, const float* __restrict__ y,
