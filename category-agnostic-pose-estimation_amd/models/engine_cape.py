@@ -261,6 +261,8 @@ def run_training(args):
     if not torch.cuda.is_available():
         raise RuntimeError("cape_amd trains on MI355X only: no GPU visible (there is no CPU fallback)")
     device = torch.device(f"cuda:{local}")
+    # host-bound step: the autograd engine stays on the calling thread (no worker hand-off per backward call)
+    torch.autograd.set_multithreading_enabled(False)
     args.device = str(device)
     seed = args.seed + rank
     torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
