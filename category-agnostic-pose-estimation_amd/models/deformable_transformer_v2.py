@@ -286,7 +286,9 @@ class DecodeWeights:
         return out
 
     def get(self):
-        key = tuple((t.data_ptr(), t._version) for t in self._sources())
+        # (the optimizer kernel updates the flat arenas behind autograd's back -- no `_version` bump: its epoch counter, the one
+        # the packed GEMM weights follow, is part of the key)
+        key = (ops.PackedWeights.epoch,) + tuple((t.data_ptr(), t._version) for t in self._sources())
         if key != self.key:
             C = self.decoder.layers[0].d_model
             layers = []

@@ -260,6 +260,13 @@ class RoomFormerV2(nn.Module):
         # the captured steps hold raw weight pointers: if the parameters were re-homed since (model.to(), arena creation,
         # load into new storage) the graphs are dropped and re-captured
         sentinel = tuple(p_.data_ptr() for p_ in list(dec.parameters())[:4]) + (self.query_embed.weight.data_ptr(),)
+        if fused:
+            # the folded inference weights are tensors of their own: captured steps (and the whole-step descriptor) point at them,
+            # so their identity (rebuilt after every optimizer step / weight load) is part of what invalidates the graphs
+            if getattr(self, "_decode_weights", None) is None:
+                self._decode_weights = DecodeWeights(dec)
+            self._decode_weights.get()
+            sentinel = sentinel + (self._decode_weights.key,)
         if st.get("weights_at") != sentinel:
             st["graphs"], st["pool"], st["weights_at"] = {}, None, sentinel
             st["calls"] = 0
@@ -315,7 +322,7 @@ class RoomFormerV2(nn.Module):
 
             plan = None
             if mega:
-                pkey = (sentinel, id(dw))
+                pkey = (sentinel, self._decode_weights.key)            # by value: the folded weights are rebuilt when a source changes
                 if st.get("plan_key") != pkey:
                     st["plan"], st["plan_key"] = self._decode_plan(dec, dw, caches, wsb["emb"], vr_s, geo, N), pkey
                 plan = st["plan"]

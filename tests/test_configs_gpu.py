@@ -153,6 +153,48 @@ def test_whole_step_decode_kernel_beyond_64_images():
     assert torch.isfinite(big["logits"]).all()
 
 
+def test_decode_follows_optimizer_steps(monkeypatch):
+    """The fused decode paths use derived inference weights (folded q|k|v projections) and captured step graphs; the fused
+    optimizer updates the flat arenas without touching autograd's version counters.  After training steps the fused decode
+    (whole-step kernel, eager and replayed graphs) must follow the new weights: same logits as the launch-per-op decode."""
+    from cape_amd.runtime.optimizer import ArenaAdamW
+    from cape_amd.hip import functional as HF
+    args, tok, model, crit = build_product(proc_sd=None)
+    tok.seq_len = 10
+    opt = ArenaAdamW(model, lr=3e-3, lr_backbone=3e-4, weight_decay=1e-4, max_norm=0.1)
+    HF.Runtime.seed(5, "cuda")
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.rand(2, 3, 256, 256, generator=g).cuda()
+    sc = torch.rand(2, 9, 2, generator=g).cuda()
+    sm = (torch.arange(9)[None, :] < torch.tensor([[6], [7]])).cuda()
+    sk = [[[0, 1], [1, 2]], [[0, 1], [2, 3]]]
+
+    def decode(mode, graph):
+        monkeypatch.setenv("CAPE_DECODE_FUSED", mode)
+        model.eval()
+        with torch.no_grad():
+            return model.forward_inference(samples=imgs, support_coords=sc, support_mask=sm, skeleton_edges=sk, graph=graph)["logits"]
+
+    for _ in range(3):                                       # eager, capture, replay: the graphs exist before the weights move
+        before = decode("1", True)
+    model.train()
+    from cape_amd.datasets.synthetic import SyntheticEpisodes
+    from cape_amd.datasets import episodic_collate_fn
+    ds = SyntheticEpisodes(tok, 2, 256, 9, 1, seed=3)
+    bt = episodic_collate_fn([ds[0], ds[1]])
+    for _ in range(2):
+        out = model(samples=bt["query_images"].cuda(), support_coords=bt["support_coords"].cuda(), support_mask=bt["support_masks"].cuda(),
+                    targets={k: v.cuda() for k, v in bt["query_targets"].items()}, skeleton_edges=bt["support_skeletons"])
+        crit(out, {k: v.cuda() for k, v in bt["query_targets"].items()})["_total"].backward()
+        opt.step(); opt.zero_grad()
+    ref = decode("0", False)                                 # launch-per-op decode straight from the parameters
+    assert (ref[:, :4] - before[:, :4]).abs().max() > 1e-3   # the weights did move
+    for graph in (False, True, True):
+        got = decode("1", graph)
+        n = min(got.shape[1], ref.shape[1])
+        assert (got[:, :n] - ref[:, :n]).abs().max() < 2e-4, graph
+
+
 def test_evaluate_cape_with_criterion(golden_dir):
     """a17: `evaluate_cape` end to end on the device (pad / trim to the target length -> HIP criterion -> PCK) against the
     reference's stats for the crafted predictions of eval_glue.npz."""
