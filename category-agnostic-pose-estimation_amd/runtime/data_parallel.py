@@ -60,6 +60,11 @@ class EpisodeDataParallel:
         for b in self.model.buffers():
             if b.is_floating_point():
                 dist.broadcast(b, src=0, group=self.pg)
+        # the broadcasts wrote parameter memory behind autograd's version counters: everything derived from the weights
+        # (packed GEMM planes, folded decode projections) follows the optimizer's epoch counter
+        from ..hip import ops
+        if torch.cuda.is_available():
+            ops.PackedWeights.invalidate_and_repack()
 
     def _build_buckets(self, bucket_elems):
         for a in self.opt.arenas:
