@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict
 // backward.  Each block walks ROWS_PER_BLOCK rows (4 waves x 8 rows), keeps dgamma/dbeta partials of
 // its columns in registers, combines the 4 waves through LDS and issues one atomic per column.
 // ---------------------------------------------------------------------------------------------
-constexpr int LN_BWD_ROWS = 16;      // rows per block (4 waves x 4 rows): twice the blocks of the first version -- a wave's rows are a serial
+#ifndef LN_BWD_ROWS_DEF
+#define LN_BWD_ROWS_DEF 16
+#endif
+constexpr int LN_BWD_ROWS = LN_BWD_ROWS_DEF;      // rows per block (4 waves x 4 rows): twice the blocks of the first version -- a wave's rows are a serial
                                       // chain of load -> reduce -> store, more waves in flight hide more of it
 
 __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ d_out_pos,
@@ -187,9 +190,117 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
     }
   }
   __syncthreads();
+#ifndef LAB_LN_NO_ATOMIC
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
     atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// The model width (C == 256): one float4 per lane and tensor, so a wave takes FOUR rows per trip with all of their loads in
+// flight together (the general kernel above walks its rows one by one: load -> two wave reductions -> store, a dependent
+// chain per row that left it at a third of the HBM rate: 75 us for 43520 rows against 22 us for the forward).  Blocks stride
+// over the rows, keep their dgamma / dbeta partial sums in registers for the whole launch and add them once (the per-16-row
+// atomics of the general kernel put 87 k adds on each of the 16 hot cache lines: 28 us of kernel became 41-76 us, depending on
+// the rows per block; here 256 blocks add once).
+// ---------------------------------------------------------------------------------------------
+constexpr int LN256_R = 4;             // rows per wave and trip
+
+constexpr int LN256_W = 16;            // waves per block: ONE block per CU, so that only 256 blocks add their dgamma / dbeta partials
+
+__global__ void __launch_bounds__(64 * LN256_W) add_ln_bwd256_kernel(const float* __restrict__ d_out, const float* __restrict__ d_out_pos,
+                                                             const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                             const float* __restrict__ rstd_i, float* __restrict__ d_x,
+                                                             float* __restrict__ d_y, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int rows, uint32_t thresh, float inv_keep,
+                                                             const uint64_t* rng_state, uint32_t rng_stream) {
+  __shared__ float red[2][LN256_W][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t seed = 0, step = 0;
+  if (thresh) { seed = rng_state[0]; step = rng_state[1]; }
+  const float4 gam = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool split = d_y && d_y != d_x;
+  const int wave_g = blockIdx.x * LN256_W + w, nwaves = gridDim.x * LN256_W;
+  for (int r0 = wave_g * LN256_R; r0 < rows; r0 += nwaves * LN256_R) {
+    float4 v[LN256_R], d[LN256_R];
+    float mean[LN256_R], rstd[LN256_R];
+    uint32_t kb[LN256_R];
+#pragma unroll
+    for (int k = 0; k < LN256_R; ++k) {                          // every load of the trip is requested before the first use
+      const int row = min(r0 + k, rows - 1);
+      const long long base = (long long)row * 256 + 4 * lane;
+      v[k] = *reinterpret_cast<const float4*>(x + base);
+      d[k] = *reinterpret_cast<const float4*>(d_out + base);
+      mean[k] = mean_i[row]; rstd[k] = rstd_i[row];
+    }
+    if (y) {
+#pragma unroll
+      for (int k = 0; k < LN256_R; ++k) {
+        const int row = min(r0 + k, rows - 1);
+        const long long base = (long long)row * 256 + 4 * lane;
+        float4 q = *reinterpret_cast<const float4*>(y + base);
+        kb[k] = 0xF;
+        if (thresh) {
+          const uint64_t idx = (uint64_t)base;
+          const bool k0 = cape_keep(seed, step, rng_stream, idx + 0, thresh), k1 = cape_keep(seed, step, rng_stream, idx + 1, thresh);
+          const bool k2 = cape_keep(seed, step, rng_stream, idx + 2, thresh), k3 = cape_keep(seed, step, rng_stream, idx + 3, thresh);
+          kb[k] = (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2) | ((uint32_t)k3 << 3);
+          q.x = k0 ? q.x * inv_keep : 0.f; q.y = k1 ? q.y * inv_keep : 0.f;
+          q.z = k2 ? q.z * inv_keep : 0.f; q.w = k3 ? q.w * inv_keep : 0.f;
+        }
+        v[k].x += q.x; v[k].y += q.y; v[k].z += q.z; v[k].w += q.w;
+      }
+    }
+    if (d_out_pos) {
+#pragma unroll
+      for (int k = 0; k < LN256_R; ++k) {
+        const int row = min(r0 + k, rows - 1);
+        const float4 e = *reinterpret_cast<const float4*>(d_out_pos + (long long)row * 256 + 4 * lane);
+        d[k].x += e.x; d[k].y += e.y; d[k].z += e.z; d[k].w += e.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LN256_R; ++k) {
+      const bool live = r0 + k < rows;                            // wave-uniform
+      float4 xh, g;
+      xh.x = (v[k].x - mean[k]) * rstd[k]; xh.y = (v[k].y - mean[k]) * rstd[k];
+      xh.z = (v[k].z - mean[k]) * rstd[k]; xh.w = (v[k].w - mean[k]) * rstd[k];
+      if (live) {
+        ag.x += d[k].x * xh.x; ag.y += d[k].y * xh.y; ag.z += d[k].z * xh.z; ag.w += d[k].w * xh.w;
+        ab.x += d[k].x; ab.y += d[k].y; ab.z += d[k].z; ab.w += d[k].w;
+      }
+      g.x = d[k].x * gam.x; g.y = d[k].y * gam.y; g.z = d[k].z * gam.z; g.w = d[k].w * gam.w;
+      const float m1 = wave_sum(g.x + g.y + g.z + g.w) * (1.f / 256.f);
+      const float m2 = wave_sum(g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w) * (1.f / 256.f);
+      float4 ds;
+      ds.x = rstd[k] * (g.x - m1 - xh.x * m2); ds.y = rstd[k] * (g.y - m1 - xh.y * m2);
+      ds.z = rstd[k] * (g.z - m1 - xh.z * m2); ds.w = rstd[k] * (g.w - m1 - xh.w * m2);
+      if (live) {
+        const long long base = (long long)(r0 + k) * 256 + 4 * lane;
+        *reinterpret_cast<float4*>(d_x + base) = ds;
+        if (split) {
+          if (thresh) {
+            ds.x = (kb[k] & 1) ? ds.x * inv_keep : 0.f; ds.y = (kb[k] & 2) ? ds.y * inv_keep : 0.f;
+            ds.z = (kb[k] & 4) ? ds.z * inv_keep : 0.f; ds.w = (kb[k] & 8) ? ds.w * inv_keep : 0.f;
+          }
+          *reinterpret_cast<float4*>(d_y + base) = ds;
+        }
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(&red[0][w][4 * lane]) = ag;
+  *reinterpret_cast<float4*>(&red[1][w][4 * lane]) = ab;
+  __syncthreads();
+  if (threadIdx.x < 512) {
+    const int which = threadIdx.x >> 8, c = threadIdx.x & 255;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN256_W; ++k) a += red[which][k][c];
+    atomicAdd((which ? dbeta : dgamma) + c, a);
   }
 }
 
@@ -318,6 +429,15 @@ extern "C" int cape_add_layernorm_bwd(const float* d_out, const float* d_out_pos
   if (rows <= 0) return 0;
   const uint32_t th = dropout_p > 0.f ? cape_drop_threshold(dropout_p) : 0u;
   const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  static const bool general_only = getenv("CAPE_LN_BWD_GENERAL") != nullptr;      // tuning switch
+  if (C == 256 && !general_only) {
+    const int trips = (rows + LN256_W * LN256_R - 1) / (LN256_W * LN256_R);      // row groups of one block-trip
+    const int blocks = trips < 256 ? trips : 256;                    // one 16-wave block per CU; more rows -> more trips per block
+    hipLaunchKernelGGL(add_ln_bwd256_kernel, dim3(blocks), dim3(64 * LN256_W), 0, as_stream(stream), d_out, d_out_pos, x, y, gamma, mean, rstd,
+                       d_x, d_y, dgamma, dbeta, rows, th, ik, rng_state, rng_stream);
+    CAPE_LAUNCH_CHECK("cape_add_layernorm_bwd");
+    return 0;
+  }
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3((rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS), dim3(256), 0, as_stream(stream),
                      d_out, d_out_pos, x, y, gamma, mean, rstd, d_x, d_y, dgamma, dbeta, rows, C, th, ik, rng_state,
                      rng_stream);
