@@ -6,8 +6,10 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* g, long long n, float* out) {
-  __shared__ float sh[4];
+// (at most 256 blocks of 16 waves: every block ends in ONE atomic add to the same address; with 2048 small blocks that
+// serialised chain was two thirds of the kernel)
+__global__ void __launch_bounds__(1024) sumsq_kernel(const float* g, long long n, float* out) {
+  __shared__ float sh[16];
   float s = 0.f;
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -18,7 +20,12 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* g, long long n,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += sh[k];
+    atomicAdd(out, a);
+  }
 }
 
 __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
@@ -51,10 +58,10 @@ extern "C" int cape_sumsq(const float* g, long long n, float* out, cape_stream_t
   CAPE_REQUIRE(g && out && n >= 0, "cape_sumsq: bad arguments");
   if (n == 0) return 0;
   CAPE_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, "cape_sumsq: g must be 16-byte aligned");
-  long long b = (n / 4 + 255) / 256;
-  if (b > 2048) b = 2048;
+  long long b = (n / 4 + 1023) / 1024;
+  if (b > 256) b = 256;
   if (b < 1) b = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)b), dim3(256), 0, as_stream(stream), g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)b), dim3(1024), 0, as_stream(stream), g, n, out);
   CAPE_LAUNCH_CHECK("cape_sumsq");
   return 0;
 }
