@@ -699,15 +699,31 @@ class MHAFn(torch.autograd.Function):
         N, Lq, C = q_in.shape
         Lk = k_in.shape[1]
         dev = q_in.device
-        q = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
-        k = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
-        v = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
-        ops.gemm(q_in.view(-1, C), in_w, q, N * Lq, C, C, bias=in_b)
-        ops.gemm(k_in.view(-1, C), in_w[C:], k, N * Lk, C, C, bias=in_b[C:])
-        ops.gemm(v_in.view(-1, C), in_w[2 * C:], v, N * Lk, C, C, bias=in_b[2 * C:])
         scale = (C // nheads) ** -0.5
         rng = Runtime.get_rng(dev) if dropout_p > 0 else None
         mm = ops.attn_mm_ok(N, nheads, Lq, Lk)      # long rows: contractions on the matrix cores, softmax kernel in between
+        # projections of the same input are ONE launch over the stacked in_proj rows (the support encoder's self-attention:
+        # q = k = v -> N = 768; cross-attention onto the support features: k = v -> N = 512); q / k / v are then column views of
+        # the wide result (row stride 3C / 2C), which the short-row attention kernels take as they are
+        merged = 0
+        if not mm and k_in is v_in:
+            merged = 3 if (q_in is k_in) else 2
+        if merged == 3:
+            qkv = torch.empty(N, Lq, 3 * C, dtype=torch.float32, device=dev)
+            ops.gemm(q_in.view(-1, C), in_w, qkv, N * Lq, 3 * C, C, bias=in_b)
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        else:
+            q = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+            ops.gemm(q_in.view(-1, C), in_w, q, N * Lq, C, C, bias=in_b)
+            if merged == 2:
+                kv = torch.empty(N, Lk, 2 * C, dtype=torch.float32, device=dev)
+                ops.gemm(k_in.view(-1, C), in_w[C:], kv, N * Lk, 2 * C, C, bias=in_b[C:])
+                k, v = kv[..., :C], kv[..., C:]
+            else:
+                k = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+                v = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+                ops.gemm(k_in.view(-1, C), in_w[C:], k, N * Lk, C, C, bias=in_b[C:])
+                ops.gemm(v_in.view(-1, C), in_w[2 * C:], v, N * Lk, C, C, bias=in_b[2 * C:])
         if mm:
             O, Pp, Pu = ops.attn_mm_fwd(q, k, v, N, nheads, Lq, Lk, scale, mask_mode=mask_mode, kpm=kpm_u8, dropout_p=dropout_p,
                                         rng=rng, rng_stream=rng_stream)
@@ -720,13 +736,13 @@ class MHAFn(torch.autograd.Function):
         ops.gemm(O.view(-1, C), out_w, out, N * Lq, C, C, bias=out_b)
         ctx.save_for_backward(q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm_u8)
         ctx.refs = (in_w, in_b, out_w, out_b)
-        ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in, mm)
+        ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in, mm, merged)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm = ctx.saved_tensors
-        nheads, mask_mode, p, stream, scale, kv_same, qk_same, mm = ctx.meta
+        nheads, mask_mode, p, stream, scale, kv_same, qk_same, mm, merged = ctx.meta
         N, Lq, C = q_in.shape
         Lk = k_in.shape[1]
         dev = d_out.device
@@ -750,7 +766,15 @@ class MHAFn(torch.autograd.Function):
                 out_grads()
         else:
             out_grads()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        if merged == 3:                              # gradients in the layout of the wide projection result
+            dqkv = torch.empty(N, Lq, 3 * C, dtype=torch.float32, device=dev)
+            dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        elif merged == 2:
+            dq = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+            dkv = torch.empty(N, Lk, 2 * C, dtype=torch.float32, device=dev)
+            dk, dv = dkv[..., :C], dkv[..., C:]
+        else:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         rng = Runtime.get_rng(dev) if p > 0 else None
         if mm:
             ops.attn_mm_bwd(dO.view(N, Lq, C), q, k, v, lse, ctx.Pu, dq, dk, dv, N, nheads, Lq, Lk, scale, dropout_p=p, rng=rng,
@@ -760,7 +784,17 @@ class MHAFn(torch.autograd.Function):
                          dropout_p=p, rng=rng, rng_stream=stream)
 
         def in_grads():
-            for i, (g, src, M) in enumerate(((dq, q_in, Mq), (dk, k_in, Mk), (dv, v_in, Mk))):
+            if merged == 3:                          # [dq | dk | dv]^T x: one product for the stacked in_proj rows
+                ops.gemm(dqkv.view(-1, 3 * C), q_in.view(-1, C), d_in_w, 3 * C, C, Mq, a_mode=1, b_mode=1, lda=3 * C, accumulate=True,
+                         split_k=ops.pick_split_k(3 * C, C, Mq), colsum_out=d_in_b)
+                return
+            ops.gemm(dq.view(-1, C), q_in.view(-1, C), d_in_w, C, C, Mq, a_mode=1, b_mode=1, accumulate=True,
+                     split_k=ops.pick_split_k(C, C, Mq), colsum_out=d_in_b)
+            if merged == 2:
+                ops.gemm(dkv.view(-1, 2 * C), k_in.view(-1, C), d_in_w[C:], 2 * C, C, Mk, a_mode=1, b_mode=1, lda=2 * C, accumulate=True,
+                         split_k=ops.pick_split_k(2 * C, C, Mk), colsum_out=d_in_b[C:])
+                return
+            for i, (g, src, M) in ((1, (dk, k_in, Mk)), (2, (dv, v_in, Mk))):
                 ops.gemm(g.view(-1, C), src.view(-1, C), d_in_w[i * C:], C, C, M, a_mode=1, b_mode=1, accumulate=True,
                          split_k=ops.pick_split_k(C, C, M), colsum_out=d_in_b[i * C:])
 
@@ -775,6 +809,22 @@ class MHAFn(torch.autograd.Function):
         # support encoder) the products accumulate into ONE buffer (GEMM epilogue C += ...) and the duplicates report None
         dq_in = dk_in = dv_in = None
         need_q, need_k, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if merged == 3 and (need_q or need_k or need_v):
+            # d x = [dq | dk | dv] . in_proj_weight: one product with K = 3C; the one tensor reports through its first live slot
+            dx = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+            ops.gemm(dqkv.view(-1, 3 * C), in_w, dx, Mq, C, 3 * C, a_mode=0, b_mode=1)
+            return ((dx if need_q else None), (dx if (need_k and not need_q) else None), (dx if (need_v and not (need_q or need_k)) else None),
+                    d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None, None)
+        if merged == 2:
+            if need_k or need_v:
+                dk_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
+                ops.gemm(dkv.view(-1, 2 * C), in_w[C:], dk_in, Mk, C, 2 * C, a_mode=0, b_mode=1)
+                if not need_k:
+                    dv_in, dk_in = dk_in, None
+            if need_q:
+                dq_in = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
+                ops.gemm(dq.view(-1, C), in_w, dq_in, Mq, C, C, a_mode=0, b_mode=1)
+            return dq_in, dk_in, dv_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None, None
         if need_k:
             dk_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
             ops.gemm(dk.view(-1, C), in_w[C:], dk_in, Mk, C, C, a_mode=0, b_mode=1)
