@@ -249,6 +249,12 @@ def ffn(x, w1, b1, w2, b2, dropout_p=0.0, rng_stream=0):
     return FFNFn.apply(x, w1, b1, w2, b2, float(dropout_p), int(rng_stream))
 
 
+def _adjacent(a, b):
+    """b starts where a ends, in the same storage (both dense, row-major)."""
+    return (a.is_contiguous() and b.is_contiguous() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+
+
 class LinearCat2Fn(torch.autograd.Function):
     """[x W1^T + b1 | x W2^T + b2]  (sampling offsets | attention logits of MSDeformAttn)."""
 
@@ -259,17 +265,22 @@ class LinearCat2Fn(torch.autograd.Function):
         x2 = _c(x).view(-1, K)
         M = x2.shape[0]
         y = torch.empty(M, N1 + N2, dtype=torch.float32, device=x.device)
-        ops.gemm(x2, w1, y, M, N1, K, bias=b1, ldc=N1 + N2)
-        ops.gemm(x2, w2, y[:, N1:], M, N2, K, bias=b2, ldc=N1 + N2)
+        # in the flat arenas the two weights (and the two biases) sit back to back (runtime/arena._colocate): one launch
+        adjacent = _adjacent(w1, w2) and _adjacent(b1, b2)
+        if adjacent:
+            ops.gemm(x2, torch.as_strided(w1, (N1 + N2, K), (K, 1)), y, M, N1 + N2, K, bias=torch.as_strided(b1, (N1 + N2,), (1,)))
+        else:
+            ops.gemm(x2, w1, y, M, N1, K, bias=b1, ldc=N1 + N2)
+            ops.gemm(x2, w2, y[:, N1:], M, N2, K, bias=b2, ldc=N1 + N2)
         ctx.save_for_backward(x2, w1, w2)
         ctx.refs = (w1, b1, w2, b2)
-        ctx.meta = (x.shape, M, N1, N2, K)
+        ctx.meta = (x.shape, M, N1, N2, K, adjacent)
         return y.view(*x.shape[:-1], N1 + N2)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w1, w2 = ctx.saved_tensors
-        xshape, M, N1, N2, K = ctx.meta
+        xshape, M, N1, N2, K, adjacent = ctx.meta
         NT = N1 + N2
         dy2 = _c(dy).view(M, NT)
         dev = dy.device
@@ -282,10 +293,14 @@ class LinearCat2Fn(torch.autograd.Function):
         sinks = [_sink(t) for t in ctx.refs]
         if all(k is not None for k in sinks):
             with _Side(dy2, x2):
-                ops.gemm(dy2, x2, sinks[0], N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M),
-                         colsum_out=sinks[1])
-                ops.gemm(dy2[:, N1:], x2, sinks[2], N2, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True,
-                         split_k=ops.pick_split_k(N2, K, M), colsum_out=sinks[3])
+                if adjacent and _adjacent(sinks[0], sinks[2]) and _adjacent(sinks[1], sinks[3]):      # the gradients mirror the layout
+                    ops.gemm(dy2, x2, torch.as_strided(sinks[0], (NT, K), (K, 1)), NT, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True,
+                             split_k=ops.pick_split_k(NT, K, M), colsum_out=torch.as_strided(sinks[1], (NT,), (1,)))
+                else:
+                    ops.gemm(dy2, x2, sinks[0], N1, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True, split_k=ops.pick_split_k(N1, K, M),
+                             colsum_out=sinks[1])
+                    ops.gemm(dy2[:, N1:], x2, sinks[2], N2, K, M, a_mode=1, b_mode=1, lda=NT, accumulate=True,
+                             split_k=ops.pick_split_k(N2, K, M), colsum_out=sinks[3])
             Runtime.notify(*[_param_of(t) for t in ctx.refs])
             return dx, None, None, None, None
         dw1 = torch.zeros(N1, K, dtype=torch.float32, device=dev)

@@ -79,4 +79,17 @@ def split_groups(model):
             backbone.append((n, p))
         else:
             main.append((n, p))
-    return main, backbone, dead
+    return _colocate(main), backbone, dead
+
+
+def _colocate(named):
+    """Physical order inside an arena is ours to choose (optimizer state and checkpoints go by name).  MSDeformAttn's
+    `sampling_offsets` and `attention_weights` always multiply the same rows: their weights are placed back to back
+    (and their biases), so that the pair is ONE (384, 256) operand for a single launch (hip/functional.LinearCat2Fn)."""
+    out = list(named)
+    for i in range(len(out) - 2):
+        a, b, c = out[i][0], out[i + 1][0], out[i + 2][0]
+        if a.endswith("sampling_offsets.weight") and b.endswith("sampling_offsets.bias") and c.endswith("attention_weights.weight") \
+                and a[:-len("sampling_offsets.weight")] == c[:-len("attention_weights.weight")]:
+            out[i + 1], out[i + 2] = out[i + 2], out[i + 1]
+    return out
