@@ -325,6 +325,42 @@ extern "C" int cape_add_f32(const float* a, const float* b, float* out, long lon
   return 0;
 }
 
+namespace {
+struct LevelStarts { int start[4]; int L; };
+__global__ void __launch_bounds__(256) level_embed_add_kernel(const float* __restrict__ base, const float* __restrict__ level_embed,
+                                                              float* __restrict__ out, LevelStarts ls, long long rows, int S, int C4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;           // one float4 per thread
+  if (i >= rows * C4) return;
+  const long long row = i / C4;
+  const int c4 = (int)(i - row * C4), s = (int)(row % S);
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) l += (k < ls.L && s >= ls.start[k]) ? 1 : 0;
+  const float4 a = reinterpret_cast<const float4*>(base)[i];
+  const float4 e = reinterpret_cast<const float4*>(level_embed)[l * C4 + c4];
+  reinterpret_cast<float4*>(out)[i] = make_float4(a.x + e.x, a.y + e.y, a.z + e.z, a.w + e.w);
+}
+}  // namespace
+
+extern "C" int cape_level_embed_add(const float* base, const float* level_embed, const int* level_start, float* out, int N, int S, int L,
+                                    int C, cape_stream_t stream) {
+  CAPE_REQUIRE(base && level_embed && level_start && out, "cape_level_embed_add: null pointer");
+  CAPE_REQUIRE(L >= 1 && L <= 4 && C > 0 && C % 4 == 0 && S > 0, "cape_level_embed_add: L=%d C=%d S=%d", L, C, S);
+  if (N <= 0) return 0;
+  CAPE_REQUIRE(((reinterpret_cast<uintptr_t>(base) | reinterpret_cast<uintptr_t>(level_embed) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+               "cape_level_embed_add: pointers must be 16-byte aligned");
+  LevelStarts ls;
+  ls.L = L;
+  for (int k = 0; k < 4; ++k) ls.start[k] = k < L ? level_start[k] : S;
+  CAPE_REQUIRE(ls.start[0] == 0, "cape_level_embed_add: level 0 starts at 0");
+  const long long rows = (long long)N * S, n4 = rows * (C / 4);
+  CAPE_REQUIRE((n4 + 255) / 256 < (1ll << 31), "cape_level_embed_add: too large");
+  hipLaunchKernelGGL(level_embed_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), base, level_embed, out, ls, rows,
+                     S, C / 4);
+  CAPE_LAUNCH_CHECK("cape_level_embed_add");
+  return 0;
+}
+
 extern "C" int cape_add_n_f32(const float* const* srcs, int k, float* out, long long n, cape_stream_t stream) {
   CAPE_REQUIRE(srcs && out && k >= 1 && k <= 8 && n >= 0, "cape_add_n_f32: 1..8 sources");
   if (n == 0) return 0;

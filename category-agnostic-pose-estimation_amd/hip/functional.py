@@ -643,6 +643,9 @@ def level_groupnorm(geo, xs, gammas, betas):
     return LevelGroupNormFn.apply(geo, *xs, *gammas, *betas)
 
 
+_SINE_CACHE = {}
+
+
 class LevelPosFn(torch.autograd.Function):
     """Image sine position embedding + level_embed, flattened (N, S, C)."""
 
@@ -651,9 +654,24 @@ class LevelPosFn(torch.autograd.Function):
         N = masks_u8[0].shape[0]
         C = level_embed.shape[1]
         out = torch.empty(N, geo.S, C, dtype=torch.float32, device=level_embed.device)
-        for l, m in enumerate(masks_u8):
-            h, w = geo.shapes[l]
-            ops.pos_sine_level(_c(m), level_embed[l], out[:, geo.starts[l]:], geo.S * C, N, h, w, C)
+        # unpadded batches hand in the cached all-False masks (util/misc.cached_zero_mask): the sine part is then a constant of the
+        # geometry, kept once (44.5 MB at 32 x 1360 x 256) -- a step only adds the trainable level_embed rows to it
+        key = (tuple(m.data_ptr() for m in masks_u8), tuple(geo.shapes), N, C, str(level_embed.device))
+        sine = _SINE_CACHE.get(key) if all(getattr(m, "_cape_all_false", False) for m in masks_u8) else None
+        if sine is None:
+            target = out
+            if all(getattr(m, "_cape_all_false", False) for m in masks_u8) and not capturing():
+                target = torch.empty_like(out)
+            zero_row = torch.zeros(C, dtype=torch.float32, device=level_embed.device) if target is not out else None
+            for l, m in enumerate(masks_u8):
+                h, w = geo.shapes[l]
+                ops.pos_sine_level(_c(m), zero_row if zero_row is not None else level_embed[l], target[:, geo.starts[l]:], geo.S * C, N, h, w, C)
+            if target is not out:
+                if len(_SINE_CACHE) >= 8:
+                    _SINE_CACHE.pop(next(iter(_SINE_CACHE)))
+                _SINE_CACHE[key] = sine = target
+        if sine is not None:
+            ops.level_embed_add(sine, _c(level_embed), geo, out)
         ctx.geo = geo
         ctx.N = N
         ctx.le_ref = level_embed

@@ -126,6 +126,7 @@ _SIGS = {
     "cape_attn_softmax_fwd": [P, P, P, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_softmax_bwd": [P, P, I, I, I, I, F, F, P, U32, P],
     "cape_add_f32": [P, P, P, LL, P],
+    "cape_level_embed_add": [P, P, P, P, I, I, I, I, P],
     "cape_add_n_f32": [POINTER(c_void_p), I, P, LL, P],
     "cape_gelu_f32": [P, P, LL, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],

@@ -616,6 +616,14 @@ def pos_sine_level(mask_u8, level_embed_l, out, out_image_stride, N, h, w, C=256
              w, C, _stream())
 
 
+def level_embed_add(base, level_embed, geo, out):
+    """out = base + level_embed[level of each token] over (N, S, C); see cape_level_embed_add."""
+    _chk(base, "level_embed_add.base"); _chk(level_embed, "level_embed_add.level_embed"); _chk(out, "level_embed_add.out")
+    N, S, C = base.shape
+    assert S == geo.S and out.shape == base.shape and level_embed.shape == (geo.L, C)
+    lib.call("cape_level_embed_add", _p(base), _p(level_embed), geo._starts_c, _p(out), N, S, geo.L, C, _stream())
+
+
 def token_embed_fwd(table, seqs, deltas):
     """seqs = (s11, s21, s12, s22) int64 (R,), deltas = (dx1, dx2, dy1, dy2) float (R,)."""
     _chk(table, "tok.table")

@@ -39,6 +39,7 @@ def cached_zero_mask(n, h, w, device, dtype=torch.bool):
     m = _ZERO_MASKS.get(key)
     if m is None:
         m = _ZERO_MASKS[key] = torch.zeros(n, h, w, dtype=dtype, device=device)
+        m._cape_all_false = True                 # lets position-embedding code treat results derived from it as constants
     return m
 
 

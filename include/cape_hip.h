@@ -310,6 +310,11 @@ int cape_attn_softmax_bwd(const float* P, float* dS, int N, int H, int Lq, int L
  * ---------------------------------------------------------------------------------------------- */
 /* out = a + b (n floats, n % 4 == 0 not required) */
 int cape_add_f32(const float* a, const float* b, float* out, long long n, cape_stream_t stream);
+/* out[n][s][:] = base[n][s][:] + level_embed[level of token s][:]  (base, out (N, S, C); level_start[l] = first token of level l).
+ * The sine part of the image position embedding is a constant of the geometry for unpadded batches (cached by the host side); this
+ * adds the trainable `level_embed` row of each level (deformable_transformer_v2.py:196 `lvl_pos_embed = pos_embed + level_embed[lvl]`). */
+int cape_level_embed_add(const float* base, const float* level_embed, const int* level_start, float* out, int N, int S, int L, int C,
+                         cape_stream_t stream);
 /* out = gelu(x), exact erf form (nn.GELU default; timm Mlp act of models/bixattn.py:116-125) */
 /* out = srcs[0] + ... + srcs[k-1] (k <= 8 host-array of device pointers, n elements each): the gradient fan-in of a tensor with
  * several consumers in one pass (what autograd's InputBuffer does with k-1 `at::add` launches). */
