@@ -256,7 +256,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   float* Ls = Ds + p.Lq;                  // lse_i
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
-  const int j = blockIdx.x * ROWS + (threadIdx.x >> 2);
+  // few keys (the 17 support keypoints): the 4-lane key groups would fill a quarter of the block and walk all Lq queries alone;
+  // the block is cut into `parts` partitions of 256 / parts threads that take every parts-th query and meet in LDS at the end
+  const int parts = p.Lk <= 16 ? 4 : (p.Lk <= 32 ? 2 : 1);
+  const int tpp = 256 / parts, part = threadIdx.x / tpp, tl = threadIdx.x - part * tpp;
+  const int j = blockIdx.x * (tpp >> 2) + (tl >> 2);
   stage_rows(Qs, Q + (long long)n * p.bsq + h * HD, p.ldq, p.Lq);
   stage_rows(Gs, dO + (long long)n * p.bso + h * HD, p.ldo, p.Lq);
   for (int r = threadIdx.x; r < p.Lq; r += blockDim.x) {
@@ -285,8 +289,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
   // causal: key j is seen by queries i >= j - offset ; wave-uniform start = min over the wave's keys
   int ibeg = 0;
-  if (p.mask_mode == 1) ibeg = max(0, blockIdx.x * ROWS + ((threadIdx.x & ~63) >> 2) - p.causal_offset);
-  for (int i = ibeg; i < p.Lq; ++i) {
+  if (p.mask_mode == 1) ibeg = max(0, blockIdx.x * (tpp >> 2) + ((tl & ~63) >> 2) - p.causal_offset);
+  for (int i = ibeg + part; i < p.Lq; i += parts) {
     const float4 q0 = *reinterpret_cast<const float4*>(Qs + i * HD + sub * 8);
     const float4 q1 = *reinterpret_cast<const float4*>(Qs + i * HD + sub * 8 + 4);
     const float4 g0 = *reinterpret_cast<const float4*>(Gs + i * HD + sub * 8);
@@ -309,7 +313,22 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     ak[0] += ds * q0.x; ak[1] += ds * q0.y; ak[2] += ds * q0.z; ak[3] += ds * q0.w;
     ak[4] += ds * q1.x; ak[5] += ds * q1.y; ak[6] += ds * q1.z; ak[7] += ds * q1.w;
   }
-  if (live) {
+  if (parts > 1) {                                               // block-uniform
+    __syncthreads();                                             // every partition is done with Qs / Gs
+    float* red = smem;                                           // [part][tl][16]
+    if (part > 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) { red[(threadIdx.x) * 16 + d] = ak[d]; red[(threadIdx.x) * 16 + 8 + d] = av[d]; }
+    }
+    __syncthreads();
+    if (part == 0) {
+      for (int q = 1; q < parts; ++q) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { ak[d] += red[(q * tpp + tl) * 16 + d]; av[d] += red[(q * tpp + tl) * 16 + 8 + d]; }
+      }
+    }
+  }
+  if (live && part == 0) {
     float* dk = dK + (long long)n * p.bsk + (long long)j * p.ldk + h * HD + sub * 8;
     float* dv = dV + (long long)n * p.bsv + (long long)j * p.ldv + h * HD + sub * 8;
     *reinterpret_cast<float4*>(dk) = make_float4(ak[0], ak[1], ak[2], ak[3]);
@@ -327,6 +346,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
 //   backward: dS = scale * P o (dPd_eff - sum_j dPd_eff P)  with dPd_eff = dropout-mask o dPd / keep      (in place)
 // The dropout decision uses the same counter-based index ((n*H + h)*Lq + i)*Lk + j as the fused kernels above.
 // ---------------------------------------------------------------------------------------------
+// (rows of up to 256 scores live in registers -- four per lane -- between the passes: one read of S / dS, one hash per element)
 __global__ void __launch_bounds__(256) attn_softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
                                                                float* __restrict__ Pd, const AttnP p) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (n*H + h)*Lq + i
@@ -338,6 +358,36 @@ __global__ void __launch_bounds__(256) attn_softmax_fwd_kernel(const float* __re
   const float* s = S + row * p.Lk;
   const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
   const int jend = p.mask_mode == 1 ? min(p.Lk, i + p.causal_offset + 1) : p.Lk;
+  uint64_t seed = 0, step = 0;
+  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  if (p.Lk <= 256) {
+    float v[4];
+    bool live[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = lane + 64 * k;
+      live[k] = j < jend && !(kp && kp[j]);
+      v[k] = live[k] ? s[j] * p.scale : -INFINITY;
+      m = fmaxf(m, v[k]);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = live[k] ? __expf(v[k] - m) : 0.f; l += v[k]; }
+    l = wave_sum(l);
+    const float inv = 1.f / l;                                               // fully masked row: 0/0 -> NaN like torch
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = lane + 64 * k;
+      if (j < p.Lk) {
+        const float pv = live[k] ? v[k] * inv : (l == 0.f ? NAN : 0.f);
+        P[row * p.Lk + j] = pv;
+        if (Pd) Pd[row * p.Lk + j] = cape_keep(seed, step, p.rng_stream, (uint64_t)row * p.Lk + j, p.thresh) ? pv * p.inv_keep : 0.f;
+      }
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int j = lane; j < jend; j += 64)
     if (!(kp && kp[j])) m = fmaxf(m, s[j] * p.scale);
@@ -346,9 +396,7 @@ __global__ void __launch_bounds__(256) attn_softmax_fwd_kernel(const float* __re
   for (int j = lane; j < jend; j += 64)
     if (!(kp && kp[j])) l += __expf(s[j] * p.scale - m);
   l = wave_sum(l);
-  const float inv = 1.f / l;                                                 // fully masked row: 0/0 -> NaN like torch
-  uint64_t seed = 0, step = 0;
-  if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
+  const float inv = 1.f / l;
   for (int j = lane; j < p.Lk; j += 64) {
     const bool live = j < jend && !(kp && kp[j]);
     const float pv = live ? __expf(s[j] * p.scale - m) * inv : (l == 0.f ? NAN : 0.f);
@@ -366,6 +414,27 @@ __global__ void __launch_bounds__(256) attn_softmax_bwd_kernel(const float* __re
   if (p.thresh) { seed = p.rng_state[0]; step = p.rng_state[1]; }
   const float* pr = P + row * p.Lk;
   float* d = dS + row * p.Lk;
+  if (p.Lk <= 256) {
+    float g[4], pv[4];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = lane + 64 * k;
+      g[k] = 0.f; pv[k] = 0.f;
+      if (j < p.Lk) {
+        g[k] = d[j]; pv[k] = pr[j];
+        if (p.thresh) g[k] = cape_keep(seed, step, p.rng_stream, (uint64_t)row * p.Lk + j, p.thresh) ? g[k] * p.inv_keep : 0.f;
+      }
+      t += g[k] * pv[k];
+    }
+    t = wave_sum(t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = lane + 64 * k;
+      if (j < p.Lk) d[j] = p.scale * pv[k] * (g[k] - t);
+    }
+    return;
+  }
   float t = 0.f;
   for (int j = lane; j < p.Lk; j += 64) {
     float g = d[j];
@@ -451,7 +520,8 @@ extern "C" int cape_attn_bwd(const float* dO, const float* Q, const float* K, co
   const size_t sh1 = (size_t)2 * Lk * HD * sizeof(float);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh1, as_stream(stream), dO, Q, K, V,
                      O, lse, dQ, p);
-  const size_t sh2 = ((size_t)2 * Lq * HD + 2 * Lq) * sizeof(float);
+  size_t sh2 = ((size_t)2 * Lq * HD + 2 * Lq) * sizeof(float);
+  if (Lk <= 32 && sh2 < 256 * 16 * sizeof(float)) sh2 = 256 * 16 * sizeof(float);      // partition reduction scratch of the few-key form
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + ROWS - 1) / ROWS, H, N), dim3(256), sh2, as_stream(stream), dO, Q, K, V,
                      O, lse, dK, dV, p);
   CAPE_LAUNCH_CHECK("cape_attn_bwd");
