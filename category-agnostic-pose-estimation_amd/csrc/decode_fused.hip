@@ -10,12 +10,16 @@
 // A CU ingests ~100 GB/s, so the step is bound at ~0.3 ms by that stream -- and weight addresses do not depend on data, so
 // the next stage's weight block is always requested before the current stage's reduction and barrier.
 //
-// Stage primitive: a wave owns 32 output rows (j = row0 + wave + 8 i) of a 256-row block and holds their 1 KB k-slices
-// in registers (32 float4 = 128 VGPRs, requested together); the input vector lives in registers (4 consecutive k per
-// lane); 32 dot products are reduced over the 64 lanes with the 32-shuffle transpose-reduce of decode_step.hip.
+// Stage primitive: a 256-row block of a weight matrix is consumed as four 64-row pieces (a wave owns 8 rows of a piece and
+// holds their 1 KB k-slices as 8 float4); the four piece buffers form a ring -- as soon as a piece has been multiplied, the
+// same piece of the NEXT block of the step's static schedule is requested into it -- so ~200 KB per CU stay in flight across
+// stage boundaries.  The input vector lives in registers (4 consecutive k per lane); the 8 dot products of a piece are reduced
+// over the 64 lanes by a transpose-reduce on the VALU (v_permlane32_swap, v_permlane16_swap, DPP row mirror, 8-lane DPP sum).
 // LayerNorms are computed by every wave redundantly from the pre-norm vector in LDS (two wave reductions, no barrier).
 // Single-query attention: wave = head (keys across lanes for q.k, channels across lanes for p.V); the deformable
 // sampling: records by wave 0, gathers by all 8 waves (2 samples each), partial sums through LDS.
+// Measured: 0.54 ms per step for 2 ... 32 images, 0.63 ms for 128 (GEMV chain alone 0.43 ms = 69 % of the stream rate).
+// LAB_NO_ATTN / LAB_NO_MSDA (compile-time) cut the attention / sampling stages out for timing the chain alone.
 // All arithmetic is plain fp32 FMA.
 #include "common.h"
 #include <stddef.h>
