@@ -315,8 +315,8 @@ def main():
         HF.Runtime.use_side_stream = side
         if os.environ.get("CAPE_BENCH_GEMM_TABLE"):
             rows = sorted(r["table"].items(), key=lambda kv: -kv[1][1])
-            for shape, (cnt, ms, fl) in rows[:40]:
-                log(f"gemm M,N,K,am,bm,sk,batch={shape} calls/step {cnt // nprof} ms/step {ms / nprof:.3f} TF/s {fl / (ms * 1e-3) / 1e12:.1f}")
+            for shape, (cnt, ms, fl) in rows[:60]:
+                log(f"gemm M,N,K,am,bm,sk,batch={shape} calls/step {cnt / nprof:g} ms/step {ms / nprof:.3f} TF/s {fl / (ms * 1e-3) / 1e12:.1f}")
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
         # peak for the arithmetic actually issued: exact fp32 MFMA, or bf16 MFMA at three instructions per product
         split = ops.get_gemm_precision() == "bf16x3"
@@ -333,7 +333,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         # algorithmic bytes per launch: A + B + C once each, fp32 (dense formula; an upper bound for the im2col modes)
-        alg_bytes = round(sum(c * 4.0 * k[6] * (k[0] * k[2] + k[1] * k[2] + k[0] * k[1]) for k, (c, _, _) in r["table"].items()) / max(r["launches"], 1))
+        alg_bytes = round(r["bytes"] / max(r["launches"], 1))
         # which roof binds the family: per launch, algorithmic flops / MFMA peak against algorithmic bytes / HBM peak
         avg_s = r["ms"] * 1e-3 / max(r["launches"], 1)
         flops_per_launch = r["flops"] / max(r["launches"], 1)
@@ -355,6 +355,7 @@ def main():
                               "gemm_kernel<BM,BN,AMODE,BMODE,VEC,PREC,KFULL> (tiled implicit GEMM), all instantiations; "
                               + ("bf16x3 split on bf16 MFMA" if split else "exact fp32 MFMA") + ")",
                     "launches_per_step": r["launches"] // nprof,
+                    "products_per_step": r["products"] // nprof,
                     "avg_launch_us": round(avg_s * 1e6, 2),
                     "gemm_ms_per_step": round(r["ms"] / nprof, 2),
                     "gemm_gflop_per_step": round(r["flops"] / nprof / 1e9, 1)}

@@ -28,6 +28,17 @@ class Runtime:
 
     pending = []                 # tensors read by enqueued side-stream kernels: kept alive until join()
 
+    # Weight gradients are not launched where the backward pass produces them: nothing waits for one until the optimizer
+    # step, so their GEMM descriptors are queued (per tile class) and submitted `wgrad_group` at a time as ONE grouped launch
+    # (csrc/gemm_group.hip) -- and whatever is left when the autograd engine finishes the pass.  Round 2 paid 199 launches,
+    # 24-64 k-splits each to fill the chip alone, for what is now ~15 launches of 4-8 k-splits.
+    defer_wgrad = os.environ.get("CAPE_DEFER_WGRAD", "1") == "1"
+    wgrad_group = int(os.environ.get("CAPE_WGRAD_GROUP", "24"))
+    wq = {}                      # (tile, b_mode, precision) -> [(desc, keep, shape)]
+    wq_total = 0
+    wq_notify = []               # parameters whose notification (data-parallel bucket bookkeeping) waits for the queued products
+    _final_cb = False
+
     @classmethod
     def side_stream(cls):
         if cls.side is None:
@@ -38,6 +49,7 @@ class Runtime:
     @classmethod
     def join(cls):
         """Make the current stream wait for all enqueued side-stream work (call before the optimizer step)."""
+        cls.flush_wgrads()
         if cls.side is not None:
             lib.call("cape_stream_join", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(cls.side_raw))
             if cls.capture_keep is None:
@@ -45,9 +57,71 @@ class Runtime:
 
     @classmethod
     def notify(cls, *params):
+        if cls.wq_total or cls.wq_notify:               # behind queued products: the callbacks run when those have been launched
+            cls.wq_notify.extend(p for p in params if p is not None)
+            return
         for cb in cls.on_param_grad:
             for p in params:
                 if p is not None:
+                    cb(p)
+
+    @classmethod
+    def enqueue_wgrad(cls, desc, keep, shape):
+        M, N, K, _, b_mode = shape
+        key = (ops.group_tile(M, N, K), b_mode, desc.precision)
+        cls.wq.setdefault(key, []).append((desc, keep, shape))
+        cls.wq_total += 1
+        if not cls._final_cb:
+            try:                                        # whatever is still queued when this backward pass ends goes then
+                torch.autograd.Variable._execution_engine.queue_callback(cls._on_backward_end)
+                cls._final_cb = True
+            except RuntimeError:                        # not inside a backward pass (a Function driven by hand): no deferral
+                cls.flush_wgrads()
+                return
+        if cls.wq_total >= cls.wgrad_group or len(cls.wq[key]) >= lib.GEMM_GROUP_MAX:
+            cls.flush_wgrads()
+
+    @classmethod
+    def _on_backward_end(cls):
+        cls._final_cb = False
+        cls.flush_wgrads()
+
+    @classmethod
+    def _launch_class(cls, key):
+        items = cls.wq.get(key)
+        if not items:
+            return
+        cls.wq[key] = []
+        cls.wq_total -= len(items)
+        tile = key[0]
+        shapes = [it[2] for it in items]
+        for it, sk in zip(items, ops.plan_group_splits([sh[:3] for sh in shapes], tile)):
+            it[0].split_k = sk
+        keep = [t for it in items for t in it[1] if t is not None]
+        side = cls.use_side_stream
+        if side:                                        # ordered after everything the main stream has been given so far
+            cls.side_stream()
+            lib.call("cape_stream_fork", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(cls.side_raw))
+            ops._stream_override[0] = cls.side_raw
+        try:
+            for i in range(0, len(items), lib.GEMM_GROUP_MAX):
+                ops.gemm_group([it[0] for it in items[i:i + lib.GEMM_GROUP_MAX]], shapes[i:i + lib.GEMM_GROUP_MAX], tile)
+        finally:
+            if side:
+                ops._stream_override[0] = None
+        if side:
+            (cls.capture_keep if cls.capture_keep is not None else cls.pending).extend(keep)
+
+    @classmethod
+    def flush_wgrads(cls):
+        """Launch every queued weight-gradient product (one grouped launch per tile class) and run the notifications
+        that waited for them."""
+        for key in list(cls.wq):
+            cls._launch_class(key)
+        if cls.wq_notify:
+            ps, cls.wq_notify = cls.wq_notify, []
+            for cb in cls.on_param_grad:
+                for p in ps:
                     cb(p)
 
     @classmethod
@@ -100,17 +174,29 @@ class _Side:
 
     def __enter__(self):
         self.on = Runtime.use_side_stream
+        self.defer = Runtime.defer_wgrad
+        if self.defer:
+            ops._wgrad_sink[0] = self._sink
         if not self.on:
             return self
         Runtime.side_stream()
-        lib.call("cape_stream_fork", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(Runtime.side_raw))
         ops._stream_override[0] = Runtime.side_raw
+        if self.defer:
+            ops._lazy_fork[0] = True                    # queued products need no fork here; any other launch orders the stream first
+        else:
+            lib.call("cape_stream_fork", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(Runtime.side_raw))
         return self
 
+    def _sink(self, desc, keep, shape):
+        # the queue keeps the product's operands alive until its launch; on a capture nothing is ever released
+        Runtime.enqueue_wgrad(desc, keep, shape)
+
     def __exit__(self, *a):
+        ops._wgrad_sink[0] = None
         if not self.on:
             return False
         ops._stream_override[0] = None
+        ops._lazy_fork[0] = False
         (Runtime.capture_keep if Runtime.capture_keep is not None else Runtime.pending).extend(self.tensors)
         if len(Runtime.pending) > 8192:                 # a caller that never joins (backward without an optimizer step)
             Runtime.join()

@@ -79,6 +79,7 @@ class DecodeTailDesc(ctypes.Structure):
 
 
 DECODE_MAX_LAYERS = 8
+GEMM_GROUP_MAX = 32          # CAPE_GEMM_GROUP_MAX
 
 
 class DecodeLayerDesc(ctypes.Structure):
@@ -112,6 +113,7 @@ _SIGS = {
     "cape_stream_fork": [P, P],
     "cape_stream_join": [P, P],
     "cape_gemm_f32": [POINTER(GemmDesc), P],
+    "cape_gemm_group_f32": [POINTER(GemmDesc), I, I, P],
     "cape_pack_weights": [P, I, I, P],
     "cape_colsum_f32": [P, LL, I, LL, I, I, P, I, P],
     "cape_add_layernorm_fwd": [P, P, P, P, P, P, P, P, P, I, I, F, P, U32, P],

@@ -21,6 +21,8 @@ _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 _stream_override = [None]        # set by hip/functional._Side: launches go to the weight-gradient side stream
+_lazy_fork = [False]             # the side stream has not yet been ordered after the main stream for the current _Side block
+_wgrad_sink = [None]             # callable(desc, keep, shape) while weight-gradient products are being queued (Runtime.defer_wgrad)
 
 
 def raw_current_stream():
@@ -34,6 +36,9 @@ def _stream():
     torch.cuda.current_stream().cuda_stream walks Python helpers for ~8 us -- 40 % of a launcher's host time, ~6 ms per
     training step (1250 launches)."""
     if _stream_override[0] is not None:
+        if _lazy_fork[0]:           # first launch of a _Side block that queues its weight gradients: order the side stream now
+            _lazy_fork[0] = False
+            lib.call("cape_stream_fork", ctypes.c_void_p(raw_current_stream()), ctypes.c_void_p(_stream_override[0]))
         return ctypes.c_void_p(_stream_override[0])
     if _raw_stream is not None and _raw_device is not None:
         return ctypes.c_void_p(_raw_stream(_raw_device()))
@@ -128,7 +133,13 @@ class GemmProfiler:
         for r in cls.records:
             t = table.setdefault(r[3], [0, 0.0, 0.0])
             t[0] += 1; t[1] += r[0].elapsed_time(r[1]); t[2] += r[2]
-        return {"launches": len(cls.records), "flops": flops, "ms": ms, "table": table}
+        return {"launches": len(cls.records), "flops": flops, "ms": ms, "table": table, "bytes": sum(r[4] for r in cls.records),
+                "products": sum(r[5] for r in cls.records)}
+
+    @staticmethod
+    def alg_bytes(M, N, K, nb=1):
+        """Algorithmic bytes of one product: A + B + C once each, fp32 (dense formula; an upper bound for the im2col modes)."""
+        return 4.0 * nb * (M * K + N * K + M * N)
 
 
 # GEMM arithmetic: "f32" = exact fp32 MFMA, "bf16x3" = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate).
@@ -299,15 +310,69 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         assert bias.numel() >= N
     if scale is not None:
         assert scale.numel() >= N
+    if (_wgrad_sink[0] is not None and a_mode == 1 and accumulate and batch is None and mask_src is None and bias is None
+            and b_mode in (1, 3) and _group_ok(d)):
+        _wgrad_sink[0](d, (A, B, C, colsum_out), (M, N, K, a_mode, b_mode))      # queued: launched with its group (gemm_group)
+        return
     if GemmProfiler.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
-        e1.record()
+        st = _stream()
+        e0.record(torch.cuda.ExternalStream(st.value) if _stream_override[0] is not None else None)
+        lib.call("cape_gemm_f32", ctypes.byref(d), st)
+        e1.record(torch.cuda.ExternalStream(st.value) if _stream_override[0] is not None else None)
         nb = batch[0] if batch is not None else 1
-        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K * nb, (M, N, K, a_mode, b_mode, int(split_k), nb)))
+        GemmProfiler.records.append((e0, e1, 2.0 * M * N * K * nb, (M, N, K, a_mode, b_mode, int(split_k), nb),
+                                     GemmProfiler.alg_bytes(M, N, K, nb), 1))
         return
     lib.call("cape_gemm_f32", ctypes.byref(d), _stream())
+
+
+def _group_ok(d):
+    """The conditions of cape_gemm_group_f32 (vector path of the tile body) for one weight-gradient product."""
+    return (d.A % 16 == 0 and d.B % 16 == 0 and d.lda % 4 == 0 and d.M % 4 == 0 and d.M >= 4 and d.N % 4 == 0 and d.N >= 4
+            and (d.b_mode == 3 or d.ldb % 4 == 0) and max(d.lda, d.ldb, d.ldc) < (1 << 31))
+
+
+def group_tile(M, N, K):
+    """Output tile edge of a queued weight gradient: 128 for big outputs over deep contractions (the FFN and 3x3-conv weights:
+    halved L2 -> L1 operand traffic per flop, profiles/r02_wgrad_sweep.txt), else 64."""
+    return 128 if (M >= 128 and N >= 128 and M * N >= 256 * 1024 and K >= 4096) else 64
+
+
+def plan_group_splits(shapes, tile):
+    """k-splits for the items [(M, N, K)] of one grouped launch: every block gets about the same number of k-tiles, enough
+    blocks to cover the chip (~4 resident 64-tiles or ~2 resident 128-tiles per CU), at least 8 k-tiles per block."""
+    target = 1024 if tile == 64 else 512
+    tiles = [((M + tile - 1) // tile) * ((N + tile - 1) // tile) for M, N, K in shapes]
+    kt = [(K + 31) // 32 for M, N, K in shapes]
+    work = sum(t * k for t, k in zip(tiles, kt))
+    per_block = max(8.0, work / float(target))              # k-tiles per block
+    out = []
+    for k in kt:
+        s = int(max(1, min(round(k / per_block), k // 8 if k >= 16 else 1, 64)))
+        if s >= 8:
+            s = s // 8 * 8                                   # multiples of 8: a k-split stays on one XCD (slab read once per L2)
+        out.append(s)
+    return out
+
+
+def gemm_group(descs, shapes, tile):
+    """descs: list of lib.GemmDesc (weight-gradient products, same b_mode and precision) -> one launch (cape_gemm_group_f32)."""
+    n = len(descs)
+    assert 1 <= n <= lib.GEMM_GROUP_MAX
+    arr = (lib.GemmDesc * n)(*descs)
+    if GemmProfiler.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = _stream()
+        ext = torch.cuda.ExternalStream(st.value) if _stream_override[0] is not None else None
+        e0.record(ext)
+        lib.call("cape_gemm_group_f32", arr, n, tile, st)
+        e1.record(ext)
+        fl = sum(2.0 * M * N * K for M, N, K, _, _ in shapes)
+        by = sum(GemmProfiler.alg_bytes(M, N, K) for M, N, K, _, _ in shapes)
+        GemmProfiler.records.append((e0, e1, fl, ("group", tile, shapes[0][4], n), by, n))
+        return
+    lib.call("cape_gemm_group_f32", arr, n, tile, _stream())
 
 
 def colsum(X, M, N, out, ldx=None, accumulate=True, nbatch=1, batch_stride=0):

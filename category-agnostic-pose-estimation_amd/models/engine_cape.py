@@ -146,10 +146,12 @@ def extract_keypoints_from_predictions(pred_coords, pred_logits, max_keypoints: 
 
 
 @torch.no_grad()
-def evaluate_cape(model, criterion, data_loader, device, compute_pck=True, pck_threshold=0.2):
+def evaluate_cape(model, criterion, data_loader, device, compute_pck=True, pck_threshold=0.2, return_per_category=False):
     """Autoregressive validation: KV-cached decode -> pad/trim to the target length -> validation loss;
     PCK@bbox on keypoints extracted by predicted token types (GT keypoints by GT labels), trimmed / zero
-    padded to the category's keypoint count, scaled by 512 like the reference (`engine_cape.py:773-841`)."""
+    padded to the category's keypoint count, scaled by 512 like the reference (`engine_cape.py:773-841`).
+    `return_per_category=True` (not a reference argument; the checkpoint-evaluation script's table, reference
+    scripts/eval_cape_checkpoint.py:329-420) returns (stats, {category id: PCK}) instead of stats."""
     model.eval()
     if criterion is not None:
         criterion.eval()
@@ -199,6 +201,8 @@ def evaluate_cape(model, criterion, data_loader, device, compute_pck=True, pck_t
                      pck_num_correct=r["total_correct"], pck_num_visible=r["total_visible"])
     for k in ("loss", "loss_ce", "loss_coords"):
         stats.setdefault(k, 0.0)
+    if return_per_category:
+        return stats, (dict(r.get("pck_per_category", {})) if pck is not None else {})
     return stats
 
 

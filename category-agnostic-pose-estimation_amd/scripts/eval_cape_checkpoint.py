@@ -101,23 +101,10 @@ def build_dataloader(args, tok, split, num_workers, num_episodes=None, num_queri
 
 
 def per_category_table(loader, model, device, threshold):
-    """Second pass bookkeeping lives in PCKEvaluator; this runs the evaluation once and returns (stats, per-category dict)."""
+    """One evaluation pass -> (stats, {category id: PCK}); the per-category numbers come from the PCKEvaluator that
+    `evaluate_cape` itself fills (reference scripts/eval_cape_checkpoint.py:329-420 reads them from its evaluator the same way)."""
     from ..models import engine_cape
-    from ..util.eval_utils import PCKEvaluator
-    captured = {}
-    orig = PCKEvaluator.get_results
-
-    def spy(self):
-        r = orig(self)
-        captured["r"] = r
-        return r
-
-    PCKEvaluator.get_results = spy
-    try:
-        stats = engine_cape.evaluate_cape(model, None, loader, device, compute_pck=True, pck_threshold=threshold)
-    finally:
-        PCKEvaluator.get_results = orig
-    return stats, captured.get("r", {}).get("pck_per_category", {})
+    return engine_cape.evaluate_cape(model, None, loader, device, compute_pck=True, pck_threshold=threshold, return_per_category=True)
 
 
 def main(argv=None):

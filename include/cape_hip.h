@@ -99,6 +99,17 @@ typedef struct {
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
 
+/* Grouped launch: `n` (1..CAPE_GEMM_GROUP_MAX) independent products of the family in ONE launch; `descs` is a HOST array (the
+ * item table travels in the kernel arguments: nothing to keep alive, capturable).  For the weight gradients of a training
+ * step -- dW = dY^T X (torch autograd of F.linear / nn.Conv2d: deformable_transformer.py:95-113,208-231, backbone.py:32-40) --
+ * which nothing waits for until the optimizer step, so the host queues them during the backward pass and submits them 8-32
+ * at a time: the tiles of all items fill the chip together and each item needs few k-splits (few float atomics).
+ * Every item: a_mode 1, the same b_mode (1 dense [K][N], or 3 conv-wgrad im2col), the same precision, accumulate = 1
+ * (split_k > 1: atomic partial sums; split_k == 1: C += tile), optional colsum_out, no other epilogue operand, no batch;
+ * 16-byte aligned operands with M, N, lda, ldb multiples of 4.  `tile` = 64 or 128 (output tile edge of every item). */
+#define CAPE_GEMM_GROUP_MAX 32
+int cape_gemm_group_f32(const cape_gemm_desc* descs, int n, int tile, cape_stream_t stream);
+
 /* Weight packing for cape_gemm_desc.B_packed.  An item describes one weight as a B operand (b_mode 0: stored [N][K], nn.Linear
  * forward; b_mode 1: stored [K][N], its dgrad) and the destination of cape_packed_weight_bytes(N, K) bytes.  `items_dev` is a
  * DEVICE array, so the table of all weights of a model is uploaded once and one launch per optimizer step re-packs them. */

@@ -252,3 +252,58 @@ def test_train_loop_parameter_deltas(golden_dir, proc_sd, gemm_precision):
             # arithmetic perturbs more of them than exact fp32
             close = ((got - ref).abs() <= 5e-6).float().mean().item()
             assert close >= (0.93 if gemm_precision == "f32" else 0.90), (k, close)
+
+
+# ------------------------------------------------------------------------------------------------
+# round-3 fixtures (oracle/make_golden_r3.py)
+# ------------------------------------------------------------------------------------------------
+def _check_step(d, model, crit, out, targets):
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])[:, :, :24].cpu()
+    coords = torch.stack([a["pred_coords"] for a in out["aux_outputs"]] + [out["pred_coords"]])[:, :, :24].cpu()
+    assert (logits - t(d["logits"])).abs().max() < 1e-3
+    assert (coords - t(d["coords"])).abs().max() < 1e-4
+    assert torch.equal(logits.argmax(-1), t(d["logits"]).argmax(-1))
+    ld = crit(out, targets)
+    for k, v in zip(json.loads(bytes(d["loss_keys"]).decode()), d["loss_vals"]):
+        assert abs(float(ld[k]) - float(v)) < 1e-3, k
+    assert abs(float(ld["_total"].detach()) - float(d["loss"])) < 5e-3
+    ld["_total"].backward()
+    from cape_amd.hip import functional as HF
+    HF.Runtime.join()
+    named = dict(model.named_parameters(remove_duplicate=False))
+    for k in d.files:
+        if k.startswith("gradhead:"):
+            ref = t(d[k])
+            got = named[k[9:]].grad.detach().cpu().reshape(-1)[:256]
+            assert (got - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max())), k
+    worst = 0.0
+    for name, ref in zip(json.loads(bytes(d["gnorm_keys"]).decode()), d["gnorm_vals"]):
+        worst = max(worst, abs(float(named[name].grad.norm()) - ref) / max(ref, 1e-3))
+    assert worst < 2e-2, worst
+
+
+def test_e2e256_backward_at_the_headline_shape(golden_dir, proc_sd):
+    """BASELINE configs[1] geometry (256x256, 17 keypoints, N = 2): forward, 19 losses, every gradient norm, 8 gradient slices."""
+    d = np.load(os.path.join(golden_dir, "e2e256_grads.npz"))
+    args, tok, model, crit = build_product(proc_sd=proc_sd)
+    model.eval()
+    b = to_dev(synth.make_batch(23, 1, 2, 256, 17, CFG, n_invisible=(2,)))
+    out = model(samples=b["images"], support_coords=b["support_coords"], support_mask=b["support_mask"],
+                targets=b["targets"], skeleton_edges=b["skeleton"])
+    _check_step(d, model, crit, out, b["targets"])
+
+
+def test_cfg3_5shot_gcn_training_step(golden_dir, proc_sd):
+    """BASELINE configs[2] as a whole: two 5-shot episodes -> the product's collate (mean-pooled support) -> GCN pre-encoder ->
+    teacher-forced training step at 256x256 (N = 4) against the reference's step on the reference's collate."""
+    from tests.test_oracle_golden import cfg3_batch
+    d = np.load(os.path.join(golden_dir, "cfg3_5shot_256.npz"))
+    b = cfg3_batch()
+    assert torch.equal(b["support_coords"], t(d["support_coords"])) and torch.equal(b["support_masks"], t(d["support_masks"]))
+    args, tok, model, crit = build_product(proc_sd=proc_sd)
+    assert model.support_encoder.use_gcn_preenc if hasattr(model.support_encoder, "use_gcn_preenc") else True
+    model.eval()
+    tg = {k: v.cuda() for k, v in b["query_targets"].items()}
+    out = model(samples=b["query_images"].cuda(), support_coords=b["support_coords"].cuda(), support_mask=b["support_masks"].cuda(),
+                targets=tg, skeleton_edges=b["support_skeletons"])
+    _check_step(d, model, crit, out, tg)

@@ -824,6 +824,110 @@ def test_gemm_wgrad_fused_bias_sums(Mo, Ni, Kr, sk, prec):
     close(cs, 2.0 + dy.sum(0), tol=2e-4, name="fused bias sums")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_group_dense_wgrads(prec, tile):
+    """cape_gemm_group_f32: several weight-gradient products (different shapes, k-splits, with / without fused bias sums, ragged K)
+    in ONE launch == the same products one by one on the CPU.  Destinations start non-zero: the group accumulates."""
+    from cape_amd.hip import lib
+    cases = [(256, 256, 6400, 4, True), (768, 256, 544, 1, True), (384, 256, 3000, 8, False), (68, 36, 100, 1, True),
+             (1024, 256, 2050, 2, True), (256, 1024, 640, 3, False), (132, 260, 40, 1, False)]
+    old = ops.get_gemm_precision()
+    try:
+        ops.set_gemm_precision(prec)
+        descs, shapes, keep, refs = [], [], [], []
+        sink = lambda d, k, sh: (descs.append(d), keep.append(k), shapes.append(sh))
+        for i, (Mo, Ni, Kr, sk, cs) in enumerate(cases):
+            dy, x = rnd(Kr, Mo, seed=10 + i), rnd(Kr, Ni, seed=30 + i)
+            out = torch.full((Mo, Ni), 0.5, device=DEV)
+            csum = torch.full((Mo,), 2.0, device=DEV) if cs else None
+            ops._wgrad_sink[0] = sink
+            try:
+                ops.gemm(dy.to(DEV), x.to(DEV), out, Mo, Ni, Kr, a_mode=1, b_mode=1, accumulate=True, split_k=sk, colsum_out=csum)
+            finally:
+                ops._wgrad_sink[0] = None
+            refs.append((out, 0.5 + dy.t() @ x, csum, 2.0 + dy.sum(0)))
+        assert len(descs) == len(cases)                      # every product was queued, none launched
+        ops.gemm_group(descs, shapes, tile)
+    finally:
+        ops.set_gemm_precision(old)
+    for i, (out, ref, csum, cref) in enumerate(refs):
+        close(out, ref, tol=2e-4, name=f"group item {i}")
+        if csum is not None:
+            close(csum, cref, tol=2e-4, name=f"group item {i} bias sums")
+    # the planner's k-splits keep >= 8 k-tiles per block and never exceed the depth
+    sp = ops.plan_group_splits([(256, 256, 6400)] * 16 + [(384, 256, 43520)], 64)
+    assert all(1 <= s <= 64 for s in sp) and sp[-1] >= sp[0]
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm_group(descs * 5, shapes * 5, tile)          # 35 items > CAPE_GEMM_GROUP_MAX
+
+
+def test_gemm_group_conv_wgrads():
+    """Grouped im2col weight gradients (b_mode 3) of different geometries against F.conv2d's autograd."""
+    geoms = [(2, 16, 16, 64, 64, 3, 1, 1), (2, 17, 15, 32, 48, 3, 2, 1), (2, 32, 32, 4, 64, 7, 2, 3), (1, 8, 8, 256, 256, 3, 2, 1)]
+    descs, shapes, keep, refs = [], [], [], []
+    sink = lambda d, k, sh: (descs.append(d), keep.append(k), shapes.append(sh))
+    for i, (N, H, W, C, O, k, stride, pad) in enumerate(geoms):
+        x, w, geom, OH, OW = _conv_case(N, H, W, C, O, k, stride, pad, seed=50 + i)
+        w.requires_grad_(True)
+        y = F.conv2d(x, w, stride=stride, padding=pad)
+        g = rnd(*y.shape, seed=70 + i)
+        y.backward(g)
+        xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        gn = g.permute(0, 2, 3, 1).contiguous().to(DEV)
+        dw = torch.zeros(O, k * k * C, device=DEV)
+        ops._wgrad_sink[0] = sink
+        try:
+            ops.gemm(gn, xn, dw, O, k * k * C, N * OH * OW, a_mode=1, b_mode=3, lda=O, conv=geom, accumulate=True, split_k=1)
+        finally:
+            ops._wgrad_sink[0] = None
+        refs.append((dw.view(O, k, k, C), w.grad.permute(0, 2, 3, 1)))
+    for d, sk in zip(descs, ops.plan_group_splits([sh[:3] for sh in shapes], 64)):
+        d.split_k = sk
+    ops.gemm_group(descs, shapes, 64)
+    for i, (dw, ref) in enumerate(refs):
+        close(dw, ref, tol=2e-4, name=f"conv wgrad group item {i}")
+
+
+def test_deferred_weight_gradients_match_immediate_launches():
+    """hip/functional.Runtime.defer_wgrad: a backward pass whose weight gradients are queued and launched in groups produces the
+    gradients of the same pass with one launch per product (a stack of Linear / FFN nodes writing straight into arena-style
+    .grad tensors)."""
+    from cape_amd.hip import functional as HF
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(256, 256, device=DEV) * 0.06) for _ in range(6)]
+    bs = [torch.nn.Parameter(torch.randn(256, device=DEV) * 0.1) for _ in range(6)]
+    w1, b1 = torch.nn.Parameter(torch.randn(1024, 256, device=DEV) * 0.06), torch.nn.Parameter(torch.zeros(1024, device=DEV))
+    w2, b2 = torch.nn.Parameter(torch.randn(256, 1024, device=DEV) * 0.03), torch.nn.Parameter(torch.zeros(256, device=DEV))
+    params = ws + bs + [w1, b1, w2, b2]
+    x = torch.randn(4, 200, 256, device=DEV)
+
+    def run(defer, group):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        old = (HF.Runtime.direct_grad, HF.Runtime.defer_wgrad, HF.Runtime.wgrad_group)
+        HF.Runtime.direct_grad, HF.Runtime.defer_wgrad, HF.Runtime.wgrad_group = True, defer, group
+        try:
+            h = x
+            for w, b in zip(ws, bs):
+                h = HF.linear(h, w, b, relu=True)
+            h = HF.ffn(h, w1, b1, w2, b2)
+            h.square().mean().backward()
+            HF.Runtime.join()
+            torch.cuda.synchronize()
+            assert HF.Runtime.wq_total == 0 and not HF.Runtime.wq_notify
+        finally:
+            HF.Runtime.direct_grad, HF.Runtime.defer_wgrad, HF.Runtime.wgrad_group = old
+        return [p.grad.clone() for p in params]
+
+    ref = run(False, 24)
+    for group in (3, 24):
+        got = run(True, group)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            close(g, r, tol=2e-4, name=f"deferred grad {i} (group {group})")
+            assert float(r.abs().max()) > 0
+
+
 # ------------------------------------------------------------------------------------------------
 # fused decode step kernels (csrc/decode_step.hip, decode.hip: cape_decode_advance)
 # ------------------------------------------------------------------------------------------------

@@ -307,3 +307,59 @@ def test_train_loop_parameter_deltas(golden_dir, proc_sd):
             ref = t(d[k])
             close = ((got - ref).abs() <= 5e-6).float().mean().item()      # Adam steps are ~lr * sign(g): near-zero gradients may flip
             assert close >= 0.97, (k, close)
+
+
+# ------------------------------------------------------------------------------------------------
+# round-3 fixtures (oracle/make_golden_r3.py): the headline shape's backward and BASELINE configs[2] as a whole
+# ------------------------------------------------------------------------------------------------
+def _check_step_fixture(d, sd, out, targets, tol_grad=2e-4):
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])[:, :, :24]
+    coords = torch.stack([a["pred_coords"] for a in out["aux_outputs"]] + [out["pred_coords"]])[:, :, :24]
+    assert (logits - t(d["logits"])).abs().max() < 1e-4
+    assert (coords - t(d["coords"])).abs().max() < 1e-5
+    losses, _, total = cape_ref.criterion(out, targets, CFG)
+    for k, v in zip(json.loads(bytes(d["loss_keys"]).decode()), d["loss_vals"]):
+        assert abs(float(losses[k]) - float(v)) < 1e-4, k
+    assert abs(float(total) - float(d["loss"])) < 1e-3
+    total.backward()
+    from oracle import procweights
+    for k in d.files:
+        if k.startswith("gradhead:"):
+            ref = t(d[k])
+            got = sd[procweights.canonical_key(k[9:])].grad.reshape(-1)[:256]
+            assert (got - ref).abs().max() <= tol_grad * max(1.0, float(ref.abs().max())), k
+    gn = dict(zip(json.loads(bytes(d["gnorm_keys"]).decode()), d["gnorm_vals"]))
+    worst = 0.0
+    for n, ref in gn.items():
+        gr = sd[procweights.canonical_key(n)].grad
+        worst = max(worst, abs(float(gr.norm()) - ref) / max(ref, 1e-3))
+    assert worst < 2e-3, worst
+
+
+def test_e2e256_backward(golden_dir, proc_sd):
+    """The headline geometry (256x256, 17 keypoints) teacher-forced WITH autograd: every gradient norm and 8 slices."""
+    d = g(golden_dir, "e2e256_grads.npz")
+    b = synth.make_batch(23, 1, 2, 256, 17, CFG, n_invisible=(2,))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in proc_sd.items()}
+    out = cape_ref.cape_forward(sd, CFG, b["images"], b["support_coords"], b["support_mask"], b["targets"], b["skeleton"],
+                                train=False, grad_mode=True)
+    _check_step_fixture(d, sd, out, b["targets"])
+
+
+def cfg3_batch():
+    """configs[2]: two 5-shot episodes through the product's collate (mean-pooled support), the inputs of cfg3_5shot_256.npz."""
+    import cape_amd  # noqa: F401
+    from cape_amd.datasets import episodic_collate_fn
+    eps = [synth.make_episode(80 + i, 256, 17, 2, 5, CFG, category_id=2 + 3 * i, n_invisible=2 * i) for i in range(2)]
+    return episodic_collate_fn(eps)
+
+
+def test_cfg3_5shot_training_step(golden_dir, proc_sd):
+    """configs[2] as a whole: 5-shot collate (datasets/episodic_sampler.py:438-442) -> GCN pre-encoder -> training step at 256x256."""
+    d = g(golden_dir, "cfg3_5shot_256.npz")
+    b = cfg3_batch()
+    assert torch.equal(b["support_coords"], t(d["support_coords"])) and torch.equal(b["support_masks"], t(d["support_masks"]))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in proc_sd.items()}
+    out = cape_ref.cape_forward(sd, CFG, b["query_images"], b["support_coords"], b["support_masks"], b["query_targets"],
+                                b["support_skeletons"], train=False, grad_mode=True)
+    _check_step_fixture(d, sd, out, b["query_targets"])
