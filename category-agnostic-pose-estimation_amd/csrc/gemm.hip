@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmP pin) {
     p.A += b0 * p.sA0 + b1 * p.sA1;
     p.B += b0 * p.sB0 + b1 * p.sB1;
     p.C += b0 * p.sC0 + b1 * p.sC1;
+    if (p.bias) p.bias += b0 * p.sBias0 + b1 * p.sBias1;
   }
   gemm_tile_body<BM, BN, AMODE, BMODE, VEC, PREC, KFULL>(p, (int)blockIdx.x);
 }
@@ -142,10 +143,12 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.mask_src = d->mask_src; p.ldm = d->ldm; p.mask_scale = d->mask_scale;
   p.bdiv = d->batch_div > 0 ? d->batch_div : 1;
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
+  p.res_cols = d->res_cols; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
+  CAPE_REQUIRE(d->res_cols >= 0 && d->res_cols % 32 == 0, "cape_gemm_f32: res_cols must be a non-negative multiple of 32");
   if (d->batch > 1)
-    CAPE_REQUIRE(d->batch <= 65535 && d->split_k == 1 && !d->bias && !d->scale && !d->residual && !d->mask_src && !d->colsum_out &&
+    CAPE_REQUIRE(d->batch <= 65535 && d->split_k == 1 && !d->scale && !d->residual && !d->mask_src && !d->colsum_out &&
                      d->dropout_p == 0.f && (d->a_mode == 0 || d->a_mode == 1) && (d->b_mode == 0 || d->b_mode == 1),
-                 "cape_gemm_f32: batched launches take dense modes, no epilogue vectors, split_k 1, batch <= 65535");
+                 "cape_gemm_f32: batched launches take dense modes, no epilogue vector besides the bias, split_k 1, batch <= 65535");
   if (d->mask_src) CAPE_REQUIRE(d->split_k == 1, "cape_gemm_f32: mask_src needs split_k == 1");
   CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
   // register-stationary weights (gemm_rs.hip): dense A against a <= 256-deep weight, the token products of the transformer

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupArgs g) {
   p.tilesM = q.tilesM; p.tilesN = q.tilesN;
   p.Bpack = nullptr; p.mask_src = nullptr; p.ldm = 0; p.mask_scale = 1.f;
   p.bdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
+  p.res_cols = 0; p.sBias0 = p.sBias1 = 0;
   gemm_tile_body<BM, BN, 1, BMODE, true, PREC, KFULL>(p, b - g.bstart[i]);
 }
 

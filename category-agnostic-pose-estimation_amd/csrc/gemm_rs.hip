@@ -98,6 +98,11 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
   // 32-bit element offsets from a wave-uniform row base (host-checked: every M * ld < 2^31)
   const int ldc = (int)p.ldc;
   const unsigned lo_c = (unsigned)(4 * h * ldc + col);
+  // EPI 1: the residual has a leading dimension of its own (q | k | v as one product, `+ query_pos` on the q columns: ldr = 256
+  // against ldc = 768) and may end at res_cols -- wave-uniform, a wave's 32 columns lie on one side of the limit
+  const int ldx = EPI == 1 ? (int)p.ldr : ldc;
+  const unsigned lo_x = (unsigned)(4 * h * ldx + col);
+  const bool res_on = EPI != 1 || !p.res_cols || n0 < p.res_cols;
 
   auto store_piece = [&](float4& v, int i, int buf) {          // one float4 of a unit: split + two 8-byte LDS stores
     unsigned short* Ph = lds + buf * 2 * G::PLANE + (st_row + RSTEP * i) * LD + 4 * st_kc;
@@ -195,18 +200,21 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
       const int half = (NW == 8) ? hh : wm;
       float xv[16];
       if constexpr (EPI >= 1 && EPI <= 3) {
-        if (col_ok) {
+        if (col_ok && res_on) {
           const int rb = u * RS_UNIT + 32 * half;
-          // (eligibility guarantees ldr == ldc / ldm == ldc: the operand shares the 32-bit lane offsets of the C stores, only
-          // its SGPR base differs -- with offsets of its own the 16 extra address registers spilled)
+          // (gate source / old C share the 32-bit lane offsets of the C stores (eligibility: ldm == ldc), only the SGPR base
+          // differs; the residual brings one lane offset of its own)
           const float* xb = EPI == 1 ? p.residual : EPI == 2 ? p.mask_src : p.C;
-          const float* x0 = xb + (long long)rb * ldc;
+          const float* x0 = xb + (long long)rb * ldx;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int roff = (i & 3) + 8 * (i >> 2);
-            if (full) xv[i] = x0[lo_c + (unsigned)(roff * ldc)];
-            else xv[i] = xb[(long long)min(rb + roff + 4 * h, p.M - 1) * ldc + col];   // ragged last unit: clamped rows, never stored
+            if (full) xv[i] = x0[lo_x + (unsigned)(roff * ldx)];
+            else xv[i] = xb[(long long)min(rb + roff + 4 * h, p.M - 1) * ldx + col];   // ragged last unit: clamped rows, never stored
           }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) xv[i] = 0.f;
         }
       }
       f32x16 acc;
@@ -365,7 +373,8 @@ bool cape_gemm_rs_eligible(const GemmP& p, int a_mode, int b_mode) {
   if (!p.Bpack && b_mode == 0 && (!al16(p.B) || p.ldb % 4 != 0)) return false;
   const long long lim = 1ll << 31;                                   // 32-bit lane offsets in the epilogue
   if ((long long)p.M * p.ldc >= lim) return false;
-  if ((p.residual && p.ldr != p.ldc) || (p.mask_src && p.ldm != p.ldc)) return false;      // the epilogue operand shares C's offsets
+  if (p.mask_src && p.ldm != p.ldc) return false;                    // the gate source shares C's lane offsets
+  if (p.residual && (long long)p.M * p.ldr >= lim) return false;
 
   return true;
 }

@@ -563,11 +563,12 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         const unsigned lo = (unsigned)(4 * lh * ldc + l31);
         const float sc = p.scale ? p.scale[colb + l31] : 1.f;
         const float bi = p.bias ? p.bias[colb + l31] : 0.f;
+        const int kind_t = (kind == 2 && p.res_cols && colb >= p.res_cols) ? 0 : kind;      // uniform: this 32-column group takes no residual
         if (kind == 1) {
           const float b0 = split == 0 ? bi : 0.f;                                  // the bias rides with the first k-split
 #pragma unroll
           for (int r = 0; r < 16; ++r) atomicAdd(c0 + (lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * ldc)), acc[i][j][r] + b0);
-        } else if (kind == 0) {
+        } else if (kind_t == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) c0[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * ldc)] = fmaxf(fmaf(acc[i][j][r], sc, bi), floor_v);
         } else {
@@ -604,7 +605,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         float* cp = p.C + (long long)row * p.ldc + col;
         if (atomic) { atomicAdd(cp, split == 0 ? v + bi : v); continue; }     // the bias rides with the first k-split
         v = v * sc + bi;
-        if (p.residual) v += p.residual[(long long)row * p.ldr + col];
+        if (p.residual && (!p.res_cols || col < p.res_cols)) v += p.residual[(long long)row * p.ldr + col];
         if (p.relu) v = fmaxf(v, 0.f);
         if (drop) v = cape_keep(seed, step, p.rng_stream, (uint64_t)row * (uint64_t)p.N + col, p.drop_thresh) ? v * p.inv_keep : 0.f;
         if (p.mask_src) v = p.mask_src[(long long)row * p.ldm + col] != 0.f ? v * p.mask_scale : 0.f;

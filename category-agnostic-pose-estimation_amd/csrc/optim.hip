@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(1024) sumsq_kernel(const float* g, long long n
 
 __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
                                                      float b1, float b2, float eps, float wd, float max_norm,
-                                                     const float* sumsq, const int64_t* step_count) {
+                                                     const float* sumsq, const int64_t* step_count, const float* lr_dev) {
+  if (lr_dev) lr = lr_dev[0];                                // the schedule's value of this step, kept on the device (replayed graphs)
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
   const float t = (float)step_count[0];
@@ -68,14 +69,14 @@ extern "C" int cape_sumsq(const float* g, long long n, float* out, cape_stream_t
 
 extern "C" int cape_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                                float eps, float weight_decay, float max_norm, const float* sumsq, const int64_t* step_count,
-                               cape_stream_t stream) {
+                               const float* lr_dev, cape_stream_t stream) {
   CAPE_REQUIRE(p && g && m && v && step_count && n >= 0, "cape_adamw_step: bad arguments");
   CAPE_REQUIRE(max_norm <= 0.f || sumsq, "cape_adamw_step: clipping needs sumsq");
   if (n == 0) return 0;
   long long b = (n + 255) / 256;
   if (b > 4096) b = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)b), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, max_norm, sumsq, step_count);
+                     weight_decay, max_norm, sumsq, step_count, lr_dev);
   CAPE_LAUNCH_CHECK("cape_adamw_step");
   return 0;
 }

@@ -179,7 +179,8 @@ def build_mp100_cape(image_set, args, defer_pixels=False):
     ann = next((p for p in cands if p.exists()), None)
     if ann is None:
         raise FileNotFoundError("Annotation file not found in any location:\n" + "\n".join(f"  - {p}" for p in cands))
-    tr = HostTransform(train=(image_set == "train"), size=512, seed=getattr(args, "seed", None))
+    from ..util import misc as utils
+    tr = HostTransform(train=(image_set == "train"), size=512, seed=getattr(args, "seed", None), rank=utils.get_rank())
     return MP100CAPE(img_folder=str(Path(args.dataset_root) / "data"), ann_file=str(ann), transforms=tr,
                      semantic_classes=args.semantic_classes, dataset_name="mp100", image_norm=args.image_norm, poly2seq=True,
                      converter_version="v3", split=image_set, vocab_size=args.vocab_size, seq_len=args.seq_len,

@@ -962,6 +962,119 @@ class MHAFn(torch.autograd.Function):
         return dq_in, dk_in, dv_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None, None
 
 
+class DecSelfAttnFn(torch.autograd.Function):
+    """The decoder layer's causal self-attention block (deformable_transformer_v2.py:323-341) as ONE node:
+        q = attn_q(tgt) + query_pos ; k = attn_k(tgt) ; v = attn_v(tgt) ; nn.MultiheadAttention(q, k, v, causal mask)
+    Round 2 ran it as 3 + 3 projection launches around the attention core (and 3 + 3 data-gradient launches, 7 weight-gradient
+    launches and a 4-way gradient sum in the backward).  Here: the three bias-free projections are one product over the stacked
+    (3C, C) weight rows with the `+ query_pos` epilogue on the q columns (attn_q / attn_k / attn_v sit back to back in the flat
+    arena); the three in_proj blocks are one batch-3 launch (block i multiplies columns [iC, (i+1)C) of the first product);
+    the backward mirrors it (one batch-3 data gradient, ONE K = 3C product for d tgt -- the gradient sum over the three
+    consumers of `tgt` happens inside the contraction), and the seven weight gradients join the deferred groups."""
+
+    @staticmethod
+    def forward(ctx, tgt, pos, wq, wk, wv, in_w, in_b, out_w, out_b, nheads, dropout_p, rng_stream):
+        N, L, C = tgt.shape
+        M = N * L
+        dev = tgt.device
+        x, pos2 = _c(tgt).view(M, C), _c(pos).view(M, C)
+        stacked = _adjacent(wq, wk) and _adjacent(wk, wv)
+        qkv1 = torch.empty(M, 3 * C, dtype=torch.float32, device=dev)
+        if stacked:
+            ops.gemm(x, torch.as_strided(wq, (3 * C, C), (C, 1)), qkv1, M, 3 * C, C, residual=pos2, ldr=C, res_cols=C)
+        else:
+            ops.gemm(x, wq, qkv1, M, C, C, ldc=3 * C, residual=pos2, ldr=C)
+            ops.gemm(x, wk, qkv1[:, C:], M, C, C, ldc=3 * C)
+            ops.gemm(x, wv, qkv1[:, 2 * C:], M, C, C, ldc=3 * C)
+        qkv2 = torch.empty(N, L, 3 * C, dtype=torch.float32, device=dev)
+        ops.gemm(qkv1, in_w, qkv2, M, C, C, lda=3 * C, ldb=C, ldc=3 * C, bias=in_b,
+                 batch=(3, 3, 0, C, 0, C * C, 0, C), bias_strides=(0, C))
+        q, k, v = qkv2[..., :C], qkv2[..., C:2 * C], qkv2[..., 2 * C:]
+        scale = (C // nheads) ** -0.5
+        rng = Runtime.get_rng(dev) if dropout_p > 0 else None
+        flash = ops.flash_attn_ok(N, nheads, L, L)
+        mm = (not flash) and ops.attn_mm_ok(N, nheads, L, L)
+        if flash:
+            O, lse = ops.flash_attn_fwd(q, k, v, N, nheads, L, L, scale, mask_mode=1, dropout_p=dropout_p, rng=rng, rng_stream=rng_stream)
+        elif mm:
+            O, Pp, Pu = ops.attn_mm_fwd(q, k, v, N, nheads, L, L, scale, mask_mode=1, dropout_p=dropout_p, rng=rng, rng_stream=rng_stream)
+            lse = Pp
+            ctx.Pu = Pu
+        else:
+            O, lse = ops.attn_fwd(q, k, v, N, nheads, L, L, scale, mask_mode=1, dropout_p=dropout_p, rng=rng, rng_stream=rng_stream)
+        out = torch.empty(N, L, C, dtype=torch.float32, device=dev)
+        ops.gemm(O.view(M, C), out_w, out, M, C, C, bias=out_b)
+        ctx.save_for_backward(x, wq, wk, wv, in_w, out_w, qkv1, qkv2, O, lse)
+        ctx.refs = (wq, wk, wv, in_w, in_b, out_w, out_b)
+        ctx.meta = (nheads, dropout_p, rng_stream, scale, mm, stacked, N, L, C)
+        ctx.flash = flash
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, wq, wk, wv, in_w, out_w, qkv1, qkv2, O, lse = ctx.saved_tensors
+        nheads, p, stream, scale, mm, stacked, N, L, C = ctx.meta
+        M = N * L
+        dev = d_out.device
+        d_out2 = _c(d_out).view(M, C)
+        sinks = [_sink(t) for t in ctx.refs]
+        direct = all(k is not None for k in sinks)
+        g = (lambda i, shape: sinks[i] if direct else torch.zeros(shape, dtype=torch.float32, device=dev))
+        d_wq, d_wk, d_wv = g(0, (C, C)), g(1, (C, C)), g(2, (C, C))
+        d_in_w, d_in_b, d_out_w, d_out_b = g(3, (3 * C, C)), g(4, (3 * C,)), g(5, (C, C)), g(6, (C,))
+        dO = torch.empty(M, C, dtype=torch.float32, device=dev)
+        ops.gemm(d_out2, out_w, dO, M, C, C, a_mode=0, b_mode=1)
+        dqkv2 = torch.empty(N, L, 3 * C, dtype=torch.float32, device=dev)
+        dq, dk, dv = dqkv2[..., :C], dqkv2[..., C:2 * C], dqkv2[..., 2 * C:]
+        q, k, v = qkv2[..., :C], qkv2[..., C:2 * C], qkv2[..., 2 * C:]
+        rng = Runtime.get_rng(dev) if p > 0 else None
+        if ctx.flash:
+            ops.flash_attn_bwd(dO.view(N, L, C), q, k, v, O, lse, dq, dk, dv, N, nheads, L, L, scale, mask_mode=1, dropout_p=p, rng=rng,
+                               rng_stream=stream)
+        elif mm:
+            ops.attn_mm_bwd(dO.view(N, L, C), q, k, v, lse, ctx.Pu, dq, dk, dv, N, nheads, L, L, scale, dropout_p=p, rng=rng, rng_stream=stream)
+        else:
+            ops.attn_bwd(dO.view(N, L, C), q, k, v, O, lse, dq, dk, dv, N, nheads, L, L, scale, mask_mode=1, dropout_p=p, rng=rng,
+                         rng_stream=stream)
+        dqkv1 = torch.empty(M, 3 * C, dtype=torch.float32, device=dev)
+        ops.gemm(dqkv2.view(M, 3 * C), in_w, dqkv1, M, C, C, a_mode=0, b_mode=1, lda=3 * C, ldb=C, ldc=3 * C,
+                 batch=(3, 3, 0, C, 0, C * C, 0, C))
+        need_x, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = None
+        if need_x:
+            dx = torch.empty(N, L, C, dtype=torch.float32, device=dev)
+            if stacked:
+                ops.gemm(dqkv1, torch.as_strided(wq, (3 * C, C), (C, 1)), dx, M, C, 3 * C, a_mode=0, b_mode=1)
+            else:
+                for i, w in enumerate((wq, wk, wv)):
+                    ops.gemm(dqkv1[:, i * C:], w, dx, M, C, C, a_mode=0, b_mode=1, lda=3 * C, accumulate=i > 0)
+
+        def wgrads():
+            Mv = dqkv2.view(M, 3 * C)
+            ops.gemm(d_out2, O.view(M, C), d_out_w, C, C, M, a_mode=1, b_mode=1, accumulate=True, split_k=ops.pick_split_k(C, C, M),
+                     colsum_out=d_out_b)
+            for i, dw in enumerate((d_wq, d_wk, d_wv)):
+                ops.gemm(Mv[:, i * C:], qkv1[:, i * C:], d_in_w[i * C:], C, C, M, a_mode=1, b_mode=1, lda=3 * C, ldb=3 * C, accumulate=True,
+                         split_k=ops.pick_split_k(C, C, M), colsum_out=d_in_b[i * C:])
+                ops.gemm(dqkv1[:, i * C:], x, dw, C, C, M, a_mode=1, b_mode=1, lda=3 * C, ldb=C, accumulate=True,
+                         split_k=ops.pick_split_k(C, C, M))
+
+        if direct:
+            with _Side(d_out2, O, dqkv2, qkv1, dqkv1, x):
+                wgrads()
+            Runtime.notify(*[_param_of(t) for t in ctx.refs])
+            grads = (None,) * 7
+        else:
+            wgrads()
+            grads = (d_wq, d_wk, d_wv, d_in_w, d_in_b, d_out_w, d_out_b)
+        dpos = dqkv1[:, :C].view(N, L, C) if need_pos else None      # (a row-strided view of the wide gradient)
+        return (dx, dpos) + grads + (None, None, None)
+
+
+def dec_self_attn(tgt, pos, wq, wk, wv, in_w, in_b, out_w, out_b, nheads=8, dropout_p=0.0, rng_stream=0):
+    return DecSelfAttnFn.apply(tgt, pos, wq, wk, wv, in_w, in_b, out_w, out_b, nheads, float(dropout_p), int(rng_stream))
+
+
 def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, nheads=8, mask_mode=0, kpm_u8=None, dropout_p=0.0, rng_stream=0):
     return MHAFn.apply(q_in, k_in, v_in, in_w, in_b, out_w, out_b, nheads, mask_mode, kpm_u8, float(dropout_p), int(rng_stream))
 

@@ -44,6 +44,7 @@ class GemmDesc(ctypes.Structure):
         ("mask_src", c_void_p), ("ldm", c_longlong), ("mask_scale", c_float),
         ("batch", c_int), ("batch_div", c_int), ("sA0", c_longlong), ("sA1", c_longlong), ("sB0", c_longlong), ("sB1", c_longlong),
         ("sC0", c_longlong), ("sC1", c_longlong),
+        ("res_cols", c_int), ("sBias0", c_longlong), ("sBias1", c_longlong),
     ]
 
 
@@ -76,6 +77,14 @@ class DecodeTailDesc(ctypes.Structure):
         ("cls_out", c_void_p), ("ld_cls", c_longlong),
         ("hs_out", c_void_p), ("ld_hs", c_longlong),
     ]
+
+
+class AugItem(ctypes.Structure):
+    """field-for-field `cape_augment_item` (include/cape_hip.h)"""
+    _fields_ = [("src", c_void_p), ("aug", c_void_p), ("out", c_void_p), ("stat", c_void_p), ("h", c_int), ("w", c_int),
+                ("M", c_float * 6), ("color_on", c_int), ("order", c_int * 4),
+                ("bright", c_float), ("contrast", c_float), ("sat", c_float), ("hue", c_float),
+                ("mode", c_int), ("noise_std", c_float), ("seed", c_uint32), ("blur_k", c_int), ("blur_w", c_float * 49)]
 
 
 DECODE_MAX_LAYERS = 8
@@ -125,11 +134,14 @@ _SIGS = {
     "cape_msda_bwd_atomic": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_bwd": [P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
+    "cape_flash_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
+    "cape_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_softmax_fwd": [P, P, P, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_softmax_bwd": [P, P, I, I, I, I, F, F, P, U32, P],
     "cape_add_f32": [P, P, P, LL, P],
     "cape_level_embed_add": [P, P, P, P, I, I, I, I, P],
     "cape_add_n_f32": [POINTER(c_void_p), I, P, LL, P],
+    "cape_augment_batch": [P, I, I, I, P, P, P],
     "cape_gelu_f32": [P, P, LL, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],
     "cape_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
@@ -157,7 +169,7 @@ _SIGS = {
     "cape_zero_rows": [P, P, LL, I, P],
     "cape_loss_fwd_bwd": [P, P, P, P, P, P, F, F, F, P, P, P, P, I, LL, P],
     "cape_sumsq": [P, LL, P, P],
-    "cape_adamw_step": [P, P, P, P, LL, F, F, F, F, F, F, P, P, P],
+    "cape_adamw_step": [P, P, P, P, LL, F, F, F, F, F, F, P, P, P, P],
     "cape_step_increment": [P, P],
     "cape_decode_next_tokens": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cape_decode_advance": [P, LL, P, LL, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P, P],

@@ -241,13 +241,26 @@ class PackedWeights:
             e["epoch"], e["version"] = cls.epoch, (b._version if b is not None else -1)
 
     @classmethod
+    def signature(cls):
+        """Identity of the registry a captured re-pack launch covers: the entry keys in table order."""
+        return tuple(cls.entries.keys())
+
+    @classmethod
+    def mark_repacked(cls):
+        """A replayed graph ran the optimizer and the re-pack launch of its capture: same bookkeeping as invalidate_and_repack."""
+        cls.epoch += 1
+        for e in cls.entries.values():
+            b = e["base"]()
+            e["epoch"], e["version"] = cls.epoch, (b._version if b is not None else -1)
+
+    @classmethod
     def clear(cls):
         cls.entries, cls._table = {}, None
 
 
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None,
-         colsum_out=None, packed=None, mask_src=None, mask_scale=1.0, batch=None):
+         colsum_out=None, packed=None, mask_src=None, mask_scale=1.0, batch=None, res_cols=0, bias_strides=None):
     """packed: the B operand as fragment-ordered bf16 planes (PackedWeights / cape_pack_weights); looked up automatically when B
     is a parameter (or a view of one) and the product is one the register-stationary kernel takes."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
@@ -264,6 +277,7 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.bias = bias.data_ptr() if bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldr = ldr if ldr is not None else N
+    d.res_cols = int(res_cols)           # residual only on columns < res_cols (0 = all)
     d.relu, d.accumulate, d.split_k = int(relu), int(accumulate), int(split_k)
     d.dropout_p = float(dropout_p)
     d.rng_state = rng.t.data_ptr() if (rng is not None and dropout_p > 0) else None
@@ -289,6 +303,9 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
         assert cnt >= 1 and div >= 1 and cnt % div == 0
         d.batch, d.batch_div = cnt, div
         d.sA0, d.sA1, d.sB0, d.sB1, d.sC0, d.sC1 = sA0, sA1, sB0, sB1, sC0, sC1
+        if bias_strides is not None:
+            d.sBias0, d.sBias1 = bias_strides
+            assert bias is not None and _avail(bias) >= (cnt // div - 1) * d.sBias0 + (div - 1) * d.sBias1 + N
         last0, last1 = cnt // div - 1, div - 1
         offA, offB, offC = last0 * sA0 + last1 * sA1, last0 * sB0 + last1 * sB1, last0 * sC0 + last1 * sC1
     else:
@@ -305,9 +322,10 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     if M > 0:
         assert _avail(C) >= offC + (M - 1) * d.ldc + N, "gemm: C too small"
     if residual is not None:
-        assert _avail(residual) >= (M - 1) * d.ldr + N, "gemm: residual too small"
+        assert res_cols % 32 == 0 and 0 <= res_cols <= N
+        assert _avail(residual) >= (M - 1) * d.ldr + (res_cols or N), "gemm: residual too small"
     if bias is not None:
-        assert bias.numel() >= N
+        assert _avail(bias) >= N
     if scale is not None:
         assert scale.numel() >= N
     if (_wgrad_sink[0] is not None and a_mode == 1 and accumulate and batch is None and mask_src is None and bias is None
@@ -514,6 +532,51 @@ def attn_fwd(Q, K, V, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=Non
     return O, lse
 
 
+FLASH_MAX_L = 224
+
+
+def flash_attn_ok(N, H, Lq, Lk):
+    """The fused matrix-core attention (csrc/flash_attn.hip) takes rows of up to 224 keys in the bf16x3 precision mode."""
+    return (os.environ.get("CAPE_FLASH_ATTN", "1") == "1" and GEMM_PRECISION == 1 and 32 <= Lq <= FLASH_MAX_L and 32 <= Lk <= FLASH_MAX_L
+            and N <= 65535 and H <= 65535)
+
+
+def _flash_views(Q, K, V, N, H, Lq, Lk):
+    for t, n, L_ in ((Q, "Q", Lq), (K, "K", Lk), (V, "V", Lk)):
+        _chk(t, "flash_attn." + n, contiguous=False)
+        assert t.dim() == 3 and t.shape[0] == N and t.shape[1] >= L_ and t.shape[2] == H * 32 and t.stride(2) == 1
+        assert t.stride(1) % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+        assert _avail(t) >= (N - 1) * t.stride(0) + (L_ - 1) * t.stride(1) + H * 32
+
+
+def flash_attn_fwd(Q, K, V, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0, rng=None, rng_stream=0):
+    """Q (N, Lq, H*32) / K, V (N, Lk, H*32) possibly strided views -> O (N, Lq, H*32) contiguous, lse (N, H, Lq)."""
+    _flash_views(Q, K, V, N, H, Lq, Lk)
+    if kpm is not None:
+        _chk(kpm, "flash_attn.kpm", dtype=torch.uint8)
+        assert kpm.numel() == N * Lk
+    O = torch.empty(N, Lq, H * 32, dtype=_F32, device=Q.device)
+    lse = torch.empty(N, H, Lq, dtype=_F32, device=Q.device)
+    lib.call("cape_flash_attn_fwd", _p(Q), _p(K), _p(V), _p(O), _p(lse), _ld(Q), _ld(K), _ld(V), H * 32, Q.stride(0), K.stride(0),
+             V.stride(0), Lq * H * 32, N, H, Lq, Lk, float(scale), mask_mode, causal_offset, _p(kpm), float(dropout_p),
+             rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+    return O, lse
+
+
+def flash_attn_bwd(dO, Q, K, V, O, lse, dQ, dK, dV, N, H, Lq, Lk, scale, mask_mode=0, causal_offset=0, kpm=None, dropout_p=0.0,
+                   rng=None, rng_stream=0):
+    _flash_views(Q, K, V, N, H, Lq, Lk)
+    _flash_views(dQ, dK, dV, N, H, Lq, Lk)
+    _chk(dO, "flash_attn_bwd.dO"); _chk(O, "flash_attn_bwd.O"); _chk(lse, "flash_attn_bwd.lse")
+    assert dO.shape == O.shape == (N, Lq, H * 32) and lse.numel() == N * H * Lq
+    assert _ld(dQ) == _ld(Q) and _ld(dK) == _ld(K) and _ld(dV) == _ld(V)
+    assert dQ.stride(0) == Q.stride(0) and dK.stride(0) == K.stride(0) and dV.stride(0) == V.stride(0)
+    ws = torch.empty(N * H * Lq, dtype=_F32, device=dO.device)
+    lib.call("cape_flash_attn_bwd", _p(dO), _p(Q), _p(K), _p(V), _p(O), _p(lse), _p(dQ), _p(dK), _p(dV), _p(ws), _ld(Q), _ld(K), _ld(V),
+             H * 32, Q.stride(0), K.stride(0), V.stride(0), Lq * H * 32, N, H, Lq, Lk, float(scale), mask_mode, causal_offset, _p(kpm),
+             float(dropout_p), rng.ptr if (rng is not None and dropout_p > 0) else None, rng_stream, _stream())
+
+
 def attn_mm_ok(N, H, Lq, Lk):
     """The matrix-core attention form (batched GEMMs + row softmax) pays off for long rows and needs aligned shapes."""
     return (os.environ.get("CAPE_ATTN_MM", "1") == "1" and Lq >= 64 and Lk >= 64 and Lq % 4 == 0 and Lk % 4 == 0 and N * H <= 65535)
@@ -590,6 +653,16 @@ def add_n(tensors):
     arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
     lib.call("cape_add_n_f32", arr, k, _p(out), out.numel(), _stream())
     return out
+
+
+def augment_batch(items_dev_u8, n, max_pixels, out_size, mean=None, std=None):
+    """items_dev_u8: device uint8 tensor holding n cape_augment_item structs (datasets/transforms.DeviceImagePipeline builds it)."""
+    _chk(items_dev_u8, "augment.items", dtype=torch.uint8)
+    assert items_dev_u8.numel() >= n * ctypes.sizeof(lib.AugItem)
+    if mean is not None:
+        _chk(mean, "augment.mean"); _chk(std, "augment.std")
+        assert mean.numel() == 3 and std.numel() == 3
+    lib.call("cape_augment_batch", _p(items_dev_u8), n, int(max_pixels), int(out_size), _p(mean), _p(std), _stream())
 
 
 def gelu(x):
@@ -853,13 +926,17 @@ def sumsq(g, out):
     lib.call("cape_sumsq", _p(g), g.numel(), _p(out), _stream())
 
 
-def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, max_norm, sumsq_t, step_t):
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, max_norm, sumsq_t, step_t, lr_dev=None):
+    """lr_dev: optional 1-element device tensor holding the learning rate (overrides `lr`; replay-safe)."""
     for t in (p, g, m, v):
         _chk(t, "adamw")
     assert p.numel() == g.numel() == m.numel() == v.numel()
     _chk(step_t, "adamw.step", dtype=torch.int64)
+    if lr_dev is not None:
+        _chk(lr_dev, "adamw.lr_dev", contiguous=False)
+        assert lr_dev.numel() == 1
     lib.call("cape_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-             float(wd), float(max_norm), _p(sumsq_t), _p(step_t), _stream())
+             float(wd), float(max_norm), _p(sumsq_t), _p(step_t), _p(lr_dev), _stream())
 
 
 def step_increment(step_t):

@@ -13,6 +13,7 @@ MI355X-first differences in *how* (results identical):
 """
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -26,6 +27,7 @@ from ..util.misc import cached_zero_mask
 from .kv_cache import KVCache, VCache
 
 _ONES_VR = {}          # (N, levels, device) -> valid ratios of an unpadded batch (read-only)
+_FUSED_SELF_ATTN = os.environ.get("CAPE_DEC_SELF_ATTN_NODE", "1") == "1"      # tuning switch: 0 = the round-2 chain of separate nodes
 
 
 def Embedding(num_embeddings, embedding_dim, padding_idx=None, zero_init=False):
@@ -80,14 +82,20 @@ class TransformerDecoderLayer(nn.Module):
         p = self.dropout2.p if self.training else 0.0
         st = self._streams
         # tensors with several consumers go through HF.fanout (one HIP launch sums their gradients)
-        t_q, t_k, t_v, t_r = HF.fanout(tgt, 4)
-        qp_q, qp_s = HF.fanout(query_pos, 2)
-        q = HF.linear(t_q, self.attn_q.weight, residual=qp_q)
-        k = HF.linear(t_k, self.attn_k.weight)
-        v = HF.linear(t_v, self.attn_v.weight)
         sa = self.self_attn
-        t2 = HF.mha(q, k, v, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.n_heads,
-                    mask_mode=1, dropout_p=p, rng_stream=st[0])
+        qp_q, qp_s = HF.fanout(query_pos, 2)
+        if _FUSED_SELF_ATTN:
+            # attn_q / attn_k / attn_v, MultiheadAttention's in_proj, the causal core and out_proj as one node (:323-341)
+            t_a, t_r = HF.fanout(tgt, 2)
+            t2 = HF.dec_self_attn(t_a, qp_q, self.attn_q.weight, self.attn_k.weight, self.attn_v.weight, sa.in_proj_weight,
+                                  sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.n_heads, dropout_p=p, rng_stream=st[0])
+        else:
+            t_q, t_k, t_v, t_r = HF.fanout(tgt, 4)
+            q = HF.linear(t_q, self.attn_q.weight, residual=qp_q)
+            k = HF.linear(t_k, self.attn_k.weight)
+            v = HF.linear(t_v, self.attn_v.weight)
+            t2 = HF.mha(q, k, v, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.n_heads,
+                        mask_mode=1, dropout_p=p, rng_stream=st[0])
         tgt = HF.add_layernorm(t_r, t2, self.norm2.weight, self.norm2.bias, dropout_p=p, rng_stream=st[1])
         if support_features is not None:
             ca = self.support_attn

@@ -26,10 +26,28 @@ from ..hip import functional as HF
 DEBUG_CAPE = os.environ.get("DEBUG_CAPE", "0") == "1"
 
 
+_PIPELINES = {}            # (device, out_size) -> datasets.transforms.DeviceImagePipeline
+
+
+def _query_images(batch, device):
+    """The (N, 3, S, S) query batch on `device`: the collated images, or -- when the dataset defers its pixels
+    (MP100CAPE(defer_pixels=True), the default of the MP-100 path) -- made on the GPU from the raw uint8 crops and their plans
+    by two launches of csrc/augment.hip on the pipeline's stream (datasets/transforms.DeviceImagePipeline)."""
+    if batch.get("query_images") is not None:
+        return batch["query_images"].to(device, non_blocking=True)
+    raw = batch["query_raw"]
+    from ..datasets.transforms import DeviceImagePipeline
+    size = raw[0][1].out_size
+    key = (str(device), size)
+    if key not in _PIPELINES:
+        _PIPELINES[key] = DeviceImagePipeline(device, out_size=size)
+    return _PIPELINES[key]([c for c, _ in raw], [p for _, p in raw])
+
+
 def _to_device(batch, device):
     q = {k: v.to(device, non_blocking=True) for k, v in batch["query_targets"].items()}
     return (batch["support_coords"].to(device, non_blocking=True), batch["support_masks"].to(device, non_blocking=True),
-            batch["query_images"].to(device, non_blocking=True), batch.get("support_skeletons", None), q)
+            _query_images(batch, device), batch.get("support_skeletons", None), q)
 
 
 def _scaled_dicts(loss_dict, weight_dict):
@@ -288,11 +306,13 @@ def run_training(args):
         # episodes of one category each; validation on the unseen categories with batch size 1
         from ..datasets import EpisodicDataset, build_mp100_cape
         split_file = str(Path(args.dataset_root) / args.category_split_file)
-        train_ds = EpisodicDataset(build_mp100_cape("train", args), split_file, split="train",
+        # pixels are made on the GPU (raw crops + plans travel through the loader); CAPE_HOST_AUGMENT=1 keeps them on the host cores
+        defer = os.environ.get("CAPE_HOST_AUGMENT", "0") != "1" and not args.image_norm
+        train_ds = EpisodicDataset(build_mp100_cape("train", args, defer_pixels=defer), split_file, split="train",
                                    num_queries_per_episode=args.num_queries_per_episode, episodes_per_epoch=args.episodes_per_epoch,
                                    seed=args.seed, load_support_images=False)
         fixed_val = getattr(args, "fixed_val_episodes", False)
-        val_ds = EpisodicDataset(build_mp100_cape("val", args), split_file, split="val",
+        val_ds = EpisodicDataset(build_mp100_cape("val", args, defer_pixels=defer), split_file, split="val",
                                  num_queries_per_episode=args.num_queries_per_episode, episodes_per_epoch=args.val_episodes_per_epoch,
                                  seed=(args.val_seed if fixed_val else args.seed + 999), fixed_episodes=fixed_val,
                                  load_support_images=False)

@@ -99,9 +99,15 @@ class EpisodeDataParallel:
         if not self._calibrated:
             return                                  # calibration step: count uses, buckets go in finish()
         need = self._uses.get(id(p))
-        if need is None or self._count[id(p)] > need:
-            self._calibrated = False                # a use pattern never seen: fall back to finish() and recount
+        if need is None:
+            self._calibrated = False                # a parameter the calibration step never saw: fall back to finish() and recount
             return
+        if self._count[id(p)] > need:
+            # its bucket went out at notification `need`; this launch accumulates an un-reduced contribution into a slot that the
+            # all-reduce may be rewriting right now: the ranks would silently diverge
+            raise RuntimeError(f"data parallel: a parameter of bucket {bi} received weight-gradient launch #{self._count[id(p)]} "
+                               f"but the calibration step counted {need} uses per backward (data-dependent control flow in the "
+                               "model?); its bucket has already been all-reduced")
         if self._count[id(p)] == need:
             self._param_done(bi)
 
@@ -116,6 +122,7 @@ class EpisodeDataParallel:
         self._seen = set()
         self._count = {}
         self._order = []
+        self._early = 0
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -158,6 +165,8 @@ class EpisodeDataParallel:
         gradient was not produced this step still hold their zeros) and joins the communication."""
         if self.world < 2:
             return
+        HF.Runtime.flush_wgrads()                   # queued weight-gradient groups and the notifications waiting for them
+        self._early = len(self._order)              # buckets that went out during the backward pass (steady state: most of them)
         ev0 = ev1 = None
         if self.comm_stream is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev0.record()          # backward fully enqueued on the main stream
@@ -177,11 +186,23 @@ class EpisodeDataParallel:
         elif any(self._count.get(k, 0) != v for k, v in self._uses.items()):
             self._uses, self._calibrated = dict(self._count), True
         order = list(self._order)
+        self.stats["launched_before_finish"] = self._early
         if self.steps_done < self.check_order_steps:
             gathered = [None] * self.world
             dist.all_gather_object(gathered, order, group=self.pg)
             if any(g != gathered[0] for g in gathered):
                 raise RuntimeError(f"data-parallel ranks launched their gradient buckets in different orders: {gathered}")
+        # every step (one small all-reduce of two integers): the ranks agree on how many notifications they saw and on a checksum
+        # of the bucket order -- a rank that took a different path through the model shows up at the step where it happens
+        chk = torch.tensor([sum(self._count.values()), sum((i + 1) * (b + 1) for i, b in enumerate(order))], dtype=torch.int64)
+        lo, hi = chk.clone(), chk.clone()
+        if self.comm_stream is not None and dist.get_backend(self.pg) == "nccl":
+            lo, hi = lo.cuda(), hi.cuda()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if not torch.equal(lo.cpu(), hi.cpu()):
+            raise RuntimeError(f"data-parallel ranks disagree on this step's gradient notifications / bucket order "
+                               f"(min {lo.tolist()}, max {hi.tolist()}, this rank {chk.tolist()})")
         self.steps_done += 1
         st = self.stats
         st["steps"] += 1

@@ -13,6 +13,7 @@ Data-parallel runs keep the eager step (the bucket all-reduces are launched from
 import torch
 
 from ..hip import functional as HF
+from ..hip import ops
 from ..models.graph_utils import DeviceSkeleton
 
 
@@ -24,6 +25,10 @@ class _Captured:
     def __init__(self, graph, static_in, static_targets, static_skel, losses, keep):
         self.graph, self.static_in, self.static_targets, self.static_skel = graph, static_in, static_targets, static_skel
         self.losses, self.keep = losses, keep
+        # the captured re-pack launch reads the packed-weight item table of this moment: keep that tensor alive, and remember
+        # which registry it describes -- a weight registered later is not in it, the graph is then dropped and re-captured
+        self.pack_table = ops.PackedWeights._table
+        self.pack_sig = ops.PackedWeights.signature()
 
 
 class GraphedTrainStep:
@@ -87,8 +92,13 @@ class GraphedTrainStep:
                 self.cache.pop(next(iter(self.cache)))
             # capture records the step without executing it; the replay below is this call's one optimizer step
             c = self.cache[key] = self._capture(images, support_coords, support_mask, targets, skeleton_edges, key[-1])
-            c.graph.replay()
+            self._replay(c)
             return c.losses
+        if c.pack_sig != ops.PackedWeights.signature():
+            # a weight was registered (or dropped) after the capture: the captured table no longer covers the registry
+            del self.cache[key]
+            self.seen[key] = self.eager_steps
+            return self(images, support_coords, support_mask, targets, skeleton_edges)
         c.static_in[0].copy_(images, non_blocking=True)
         c.static_in[1].copy_(support_coords, non_blocking=True)
         c.static_in[2].copy_(support_mask, non_blocking=True)
@@ -98,5 +108,13 @@ class GraphedTrainStep:
         if flat:
             c.static_skel.edges[:len(flat)].copy_(torch.tensor(flat, dtype=torch.int32), non_blocking=False)
         c.static_skel.start.copy_(torch.tensor(start, dtype=torch.int32), non_blocking=False)
-        c.graph.replay()
+        self._replay(c)
         return c.losses
+
+    def _replay(self, c):
+        self.optimizer.sync_lr()                # the schedule's learning rates live on the device: uploaded here if they moved
+        c.graph.replay()
+        # the replayed optimizer kernel rewrote the arenas and the replayed pack launch refreshed every registered plane: advance
+        # the epoch that everything derived from the weights keys on (folded decode projections, decode graphs) and mark the
+        # registry current for it -- ArenaAdamW.step() does this in Python only once, at capture
+        ops.PackedWeights.mark_repacked()

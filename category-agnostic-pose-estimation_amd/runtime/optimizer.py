@@ -33,12 +33,24 @@ class ArenaAdamW(torch.optim.Optimizer):
         groups = [{"params": self.arenas[0].params, "lr": lr}, {"params": self.arenas[1].params, "lr": lr_backbone}]
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.step_count = torch.zeros(1, dtype=torch.int64, device=device)
+        # learning rates as device scalars (one per group): the AdamW kernel reads them there, so a step captured into a hipGraph
+        # keeps following the schedule -- `sync_lr` uploads param_groups[i]["lr"] when a scheduler changed it
+        self.lr_dev = torch.tensor([lr, lr_backbone], dtype=torch.float32, device=device)
+        self._lr_host = [lr, lr_backbone]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         # weight-gradient kernels may now accumulate straight into the gradient arenas (hip/functional.py)
         HF.Runtime.direct_grad = device.type == "cuda"
 
+    def sync_lr(self):
+        """Upload the groups' learning rates if a scheduler moved them (never inside a capture: call before a replay)."""
+        cur = [float(g["lr"]) for g in self.param_groups]
+        if cur != self._lr_host and not (self.lr_dev.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.lr_dev.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=False)
+            self._lr_host = cur
+
     @torch.no_grad()
     def step(self, closure=None):
+        self.sync_lr()
         HF.Runtime.join()                       # side-stream wgrad kernels must have landed in the arenas
         self.sumsq.zero_()
         if self.max_norm > 0:
@@ -46,11 +58,11 @@ class ArenaAdamW(torch.optim.Optimizer):
                 if a.numel:
                     ops.sumsq(a.grad, self.sumsq)
         ops.step_increment(self.step_count)
-        for a, g in zip(self.arenas, self.param_groups):
+        for gi, (a, g) in enumerate(zip(self.arenas, self.param_groups)):
             if a.numel:
                 b1, b2 = g["betas"]
                 ops.adamw_step(a.data, a.grad, a.exp_avg, a.exp_avg_sq, g["lr"], b1, b2, g["eps"], g["weight_decay"],
-                               self.max_norm, self.sumsq, self.step_count)
+                               self.max_norm, self.sumsq, self.step_count, lr_dev=self.lr_dev[gi:gi + 1] if self.lr_dev.is_cuda else None)
         # the kernel above rewrote every weight behind autograd's version counters: re-pack the MFMA-fragment copies the
         # register-stationary GEMM reads (one launch over the registered table)
         ops.PackedWeights.invalidate_and_repack()

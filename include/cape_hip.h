@@ -95,6 +95,11 @@ typedef struct {
      b = b0 * batch_div + b1 offsets A / B / C by b0 * s?0 + b1 * s?1 elements -- e.g. the per-(image, head) Q K^T and P V
      products of attention with heads interleaved in the rows (b0 = image, b1 = head, s?1 = 32). batch <= 1 = single product. */
   int batch, batch_div; long long sA0, sA1, sB0, sB1, sC0, sC1;
+  /* round 3 (ABI 8).  res_cols: 0 = the residual applies to every column; else (a multiple of 32) only to columns < res_cols
+     -- q | k | v of the decoder's self-attention as ONE product over the stacked attn_q / attn_k / attn_v rows, with
+     `+ query_pos` on the q columns only (deformable_transformer_v2.py:323-331).  sBias0 / sBias1: per-batch offsets of `bias`
+     for batched launches (the three in_proj blocks of nn.MultiheadAttention as one batch-3 launch). */
+  int res_cols; long long sBias0, sBias1;
 } cape_gemm_desc;
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
@@ -314,6 +319,24 @@ int cape_attn_softmax_fwd(const float* S, float* P, float* Pd, int N, int H, int
 int cape_attn_softmax_bwd(const float* P, float* dS, int N, int H, int Lq, int Lk, float scale, float dropout_p,
                           const uint64_t* rng_state, uint32_t rng_stream, cape_stream_t stream);
 
+/* Fused attention core on the matrix cores (csrc/flash_attn.hip; round 3): rows of up to 224 keys, head dim 32, bf16x3 split.
+ * One launch computes O = dropout(softmax(scale Q K^T + mask)) V and the log-sum-exp `lse` (N, H, Lq) of the scaled, masked
+ * scores -- the (N, H, Lq, Lk) score / probability tensors never leave registers.  cape_flash_attn_bwd recomputes P from
+ * `lse` (two launches: dQ and D = rowsum(dO o O) into `d_ws` (N*H*Lq floats); then dK | dV).  Layouts, strides, mask modes
+ * (0 none, 1 causal with offset, 2 key padding) and the dropout element index are those of cape_attn_fwd / cape_attn_bwd;
+ * dQ / dK / dV use the strides of Q / K / V, dO those of O.  All row strides multiples of 4 floats, bases 16-byte aligned.
+ * Replaces the core of nn.MultiheadAttention in the decoder's causal self-attention (deformable_transformer_v2.py:323-341;
+ * torch: F.scaled_dot_product_attention semantics with attention dropout). */
+int cape_flash_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* lse, long long ldq, long long ldk,
+                        long long ldv, long long ldo, long long bsq, long long bsk, long long bsv, long long bso, int N, int H,
+                        int Lq, int Lk, float scale, int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p,
+                        const uint64_t* rng_state, uint32_t rng_stream, cape_stream_t stream);
+int cape_flash_attn_bwd(const float* dO, const float* Q, const float* K, const float* V, const float* O, const float* lse,
+                        float* dQ, float* dK, float* dV, float* d_ws, long long ldq, long long ldk, long long ldv, long long ldo,
+                        long long bsq, long long bsk, long long bsv, long long bso, int N, int H, int Lq, int Lk, float scale,
+                        int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
+                        uint32_t rng_stream, cape_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / small ops.  `dim_t` = device float[128] temperature table
@@ -432,7 +455,9 @@ int cape_loss_fwd_bwd(const float* logits, const float* coords, const int64_t* l
 int cape_sumsq(const float* g, long long n, float* out, cape_stream_t stream);
 int cape_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_norm, const float* sumsq,
-                    const int64_t* step_count, cape_stream_t stream);
+                    const int64_t* step_count, const float* lr_dev /* device scalar overriding `lr` when not NULL: a captured
+                    step follows the learning-rate schedule (torch.optim.lr_scheduler writes param_groups[i]["lr"]) */,
+                    cape_stream_t stream);
 int cape_step_increment(int64_t* step_count, cape_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -450,6 +475,31 @@ int cape_decode_next_tokens(const float* cls_logits, const float* reg, int32_t* 
                             int64_t* tok /* (4,N): 11,12,21,22 */, float* delta /* (4,N): x1,x2,y1,y2 */,
                             const int32_t* step /* device scalar */, int N, int num_bins, int min_len,
                             int eos_id, int sep_id, int pad_id, cape_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GPU side of the MP-100 loader (csrc/augment.hip): raw uint8 crops -> augmented, resized, normalised
+ * (3, S, S) fp32 images, two launches per batch.  Replaces the albumentations pipeline the reference runs on the host cores for
+ * every crop (datasets/mp100_cape.py:896-950: Affine, HorizontalFlip, ColorJitter, OneOf(GaussNoise, GaussianBlur, MotionBlur),
+ * Resize).  An item is one image and its *plan* (the random numbers of those transforms, drawn by the DataLoader worker:
+ * datasets/transforms.py): aug pixel (x, y) samples source pixel (M0 x + M1 y + M2, M3 x + M4 y + M5) bilinearly with zero padding
+ * (affine about the centre + flip); colour jitter in `order` (0 brightness, 1 contrast about the image's mean grey, 2 saturation,
+ * 3 hue), each clipped to [0, 1]; mode 1 adds N(0, noise_std) from the counter RNG (seed, channel, pixel), mode 2 convolves with
+ * the blur_k x blur_k kernel (reflect-101 border); then bilinear resize to S x S (half-pixel centres, edge clamp) and
+ * (x - mean[c]) / std[c] when mean != NULL.  `items_dev` is a DEVICE array; `aug` is an (h, w, 3) fp32 workspace per item,
+ * `stat` one float per item that the caller zeroes.  max_pixels = the largest h * w of the batch.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t* src; float* aug; float* out; float* stat;
+  int h, w;
+  float M[6];
+  int color_on, order[4];
+  float bright, contrast, sat, hue;
+  int mode;
+  float noise_std; uint32_t seed;
+  int blur_k; float blur_w[49];
+} cape_augment_item;
+int cape_augment_batch(const cape_augment_item* items_dev, int n_items, int max_pixels, int out_size, const float* mean,
+                       const float* stdv, cape_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,62 @@ def test_decode_follows_optimizer_steps(monkeypatch):
         assert (got[:, :n] - ref[:, :n]).abs().max() < 2e-4, graph
 
 
+def test_decode_follows_graph_replayed_optimizer_steps(monkeypatch):
+    """the optimizer step of a REPLAYED GraphedTrainStep never runs ArenaAdamW.step() in Python, so nothing advanced the
+    epoch that the derived weights key on (packed GEMM planes, folded decode projections, captured decode graphs).  Train through
+    eager -> capture -> replay -> replay, a learning-rate change in between (the kernel reads the rate from the device), then the
+    fused decode must agree with the launch-per-op decode straight from the parameters."""
+    from cape_amd.hip import functional as HF
+    from cape_amd.hip import ops
+    from cape_amd.runtime.graph_step import GraphedTrainStep
+    from cape_amd.runtime.optimizer import ArenaAdamW
+    args, tok, model, crit = build_product(proc_sd=None)
+    tok.seq_len = 10
+    opt = ArenaAdamW(model, lr=3e-3, lr_backbone=3e-4, weight_decay=1e-4, max_norm=0.1)
+    HF.Runtime.seed(5, "cuda")
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.rand(2, 3, 256, 256, generator=g).cuda()
+    sc = torch.rand(2, 9, 2, generator=g).cuda()
+    sm = (torch.arange(9)[None, :] < torch.tensor([[6], [7]])).cuda()
+    sk = [[[0, 1], [1, 2]], [[0, 1], [2, 3]]]
+
+    def decode(mode, graph):
+        monkeypatch.setenv("CAPE_DECODE_FUSED", mode)
+        model.eval()
+        with torch.no_grad():
+            return model.forward_inference(samples=imgs, support_coords=sc, support_mask=sm, skeleton_edges=sk, graph=graph)["logits"]
+
+    for _ in range(3):
+        before = decode("1", True)
+    from cape_amd.datasets import episodic_collate_fn
+    from cape_amd.datasets.synthetic import SyntheticEpisodes
+    ds = SyntheticEpisodes(tok, 2, 256, 9, 1, seed=3)
+    bt = episodic_collate_fn([ds[0], ds[1]])
+    tg = {k: v.cuda() for k, v in bt["query_targets"].items()}
+    step = GraphedTrainStep(model, crit, opt, edge_capacity=64, eager_steps=1)
+    model.train()
+    epoch0 = ops.PackedWeights.epoch
+    probe = model.base_model.transformer.decoder.layers[0].linear1.weight
+    w_prev = probe.detach().clone()
+    moved = []
+    for i in range(4):                                       # eager, capture + replay, replay, replay (with a new learning rate)
+        if i == 3:
+            for gr in opt.param_groups:
+                gr["lr"] = gr["lr"] * 0.1
+        step(bt["query_images"].cuda(), bt["support_coords"].cuda(), bt["support_masks"].cuda(), tg, bt["support_skeletons"])
+        torch.cuda.synchronize()
+        moved.append(float((probe.detach() - w_prev).abs().max()))
+        w_prev = probe.detach().clone()
+    assert len(step.cache) == 1 and ops.PackedWeights.epoch >= epoch0 + 4
+    assert all(m > 0 for m in moved) and moved[3] < 0.35 * moved[2], moved       # the replay followed the schedule (lr x 0.1)
+    ref = decode("0", False)
+    assert (ref[:, :4] - before[:, :4]).abs().max() > 1e-3
+    for graph in (False, True, True):
+        got = decode("1", graph)
+        n = min(got.shape[1], ref.shape[1])
+        assert (got[:, :n] - ref[:, :n]).abs().max() < 2e-4, graph
+
+
 def test_evaluate_cape_with_criterion(golden_dir):
     """a17: `evaluate_cape` end to end on the device (pad / trim to the target length -> HIP criterion -> PCK) against the
     reference's stats for the crafted predictions of eval_glue.npz."""

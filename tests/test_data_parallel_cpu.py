@@ -95,6 +95,20 @@ def _worker(rank, world, port, q):
     want_uw = 3 * (1.0 + 0) / 1 + 3 * (1.0 + 1)              # sum over ranks of 3 adds each
     ok = ok and torch.allclose(uw.grad, torch.full_like(uw.grad, want_uw)) and torch.allclose(ub.grad, torch.full_like(ub.grad, 4.0))
     ok = ok and ddp.stats["steps"] == 4 and ddp.stats["bytes_per_step"] == 4 * sum(a.numel for a in opt.arenas)
+    # ---- a notification beyond the calibrated use count arrives AFTER the bucket was all-reduced: hard error, not a
+    # silent recount (both ranks raise at the same notification, no collective is left half-entered)
+    opt.zero_grad()
+    (model(xs[0]).sum() * ddp.loss_scale).backward()
+    raised = False
+    try:
+        for k in range(4):
+            uw.grad.add_(1.0)
+            ddp._on_direct_grad(uw)
+    except RuntimeError as e:
+        raised = "calibration step counted 3 uses" in str(e)
+    ok = ok and raised
+    ub.grad.add_(2.0); ddp._on_direct_grad(ub)
+    ddp.finish()                                             # the step still completes on both ranks (same counts everywhere)
     q.put((rank, ok, [n for n, _ in opt.dead]))
     dist.destroy_process_group()
 

@@ -17,7 +17,7 @@ from oracle import refshim
 import cape_amd  # noqa: F401
 from cape_amd.datasets import (EpisodicDataset, ImageNotFoundError, MP100CAPE, build_episodic_dataloader, episodic_collate_fn)
 from cape_amd.datasets.coco_lite import COCO
-from cape_amd.datasets.transforms import DeviceImagePipeline, HostTransform, apply_plan_host, resize_plan, train_plan
+from cape_amd.datasets.transforms import HostTransform, apply_plan_host, images_from_raw_host, resize_plan, train_plan
 
 needs_ref = pytest.mark.skipif(not refshim.reference_available(), reason="reference checkout not present")
 
@@ -105,8 +105,7 @@ def test_transform_plans_move_pixels_and_keypoints_together():
         blob = np.exp(-(((xx + 0.5 - kx) ** 2 + (yy + 0.5 - ky) ** 2) / 8.0))
         img[..., 0] = (blob * 255).astype(np.uint8)
         plan = train_plan(h, w, rng, size=128) if trial else resize_plan(h, w, 128)
-        plan.brightness = plan.contrast = plan.saturation = 1.0
-        plan.noise_std = 0.0
+        plan.color, plan.mode = None, 0                     # geometry only
         out = apply_plan_host(img, plan)[0]
         (mx, my), = plan.map_keypoints([(kx, ky)])
         if not (4 < mx < 124 and 4 < my < 124):
@@ -115,12 +114,23 @@ def test_transform_plans_move_pixels_and_keypoints_together():
         vy, vx = torch.meshgrid(torch.arange(128.0) + 0.5, torch.arange(128.0) + 0.5, indexing="ij")
         cx, cy = float((m * vx).sum()), float((m * vy).sum())
         assert abs(cx - mx) < 1.0 and abs(cy - my) < 1.0, (trial, cx, cy, mx, my)
-    # the device pipeline (on the CPU device here) produces the host pixels
+    # every branch of the training distribution is drawn and runs: colour orders, noise, Gaussian and motion blur, flips
     crop = rng.integers(0, 256, (70, 50, 3), dtype=np.uint8)
-    plan = train_plan(70, 50, np.random.default_rng(9), size=64)
-    a = apply_plan_host(crop, plan)
-    b = DeviceImagePipeline("cpu", out_size=64)([crop], [plan])[0]
-    assert torch.allclose(a, b, atol=1e-6)
+    seen = set()
+    g = np.random.default_rng(9)
+    for _ in range(60):
+        plan = train_plan(70, 50, g, size=64)
+        a = apply_plan_host(crop, plan)
+        assert a.shape == (3, 64, 64) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6 and torch.isfinite(a).all()
+        seen.add((plan.mode, plan.color is not None, plan.flipped, None if plan.blur_kernel is None else plan.blur_kernel.shape[0]))
+        if plan.blur_kernel is not None:
+            assert abs(float(plan.blur_kernel.sum()) - 1.0) < 1e-5
+    assert {m for m, *_ in seen} == {0, 1, 2} and {k for *_, k in seen} >= {None, 3, 5}
+    # identity plan = plain bilinear resize of the crop
+    ident = apply_plan_host(crop, resize_plan(70, 50, 64))
+    ref = torch.nn.functional.interpolate(torch.from_numpy(crop).permute(2, 0, 1)[None].float() / 255.0, size=(64, 64), mode="bilinear",
+                                          align_corners=False)[0]
+    assert torch.allclose(ident, ref, atol=1e-6)
 
 
 def test_episodic_dataset_and_loader(tmp_path):
@@ -145,14 +155,14 @@ def test_episodic_dataset_and_loader(tmp_path):
                                    num_workers=0, seed=1)
     nb = sum(1 for _ in dl)
     assert nb == 2
-    # deferred pixels: raw crops + plans travel, the pipeline makes the batch (here on the CPU device)
+    # deferred pixels: raw crops + plans travel, the pipeline makes the batch (its host counterpart here; the GPU one in tests/test_augment_gpu.py)
     ds2 = MP100CAPE(str(tmp_path / "data"), str(ann), HostTransform(train=False, size=64), vocab_size=2000, seq_len=200, defer_pixels=True)
     ep2 = EpisodicDataset(ds2, str(tmp_path / "category_splits.json"), split="train", episodes_per_epoch=2, seed=5, fixed_episodes=True,
                           load_support_images=False)
     ep1 = EpisodicDataset(ds, str(tmp_path / "category_splits.json"), split="train", episodes_per_epoch=2, seed=5, fixed_episodes=True)
     b2, b1 = episodic_collate_fn([ep2[0]]), episodic_collate_fn([ep1[0]])
     assert b2["query_images"] is None and len(b2["query_raw"]) == 2
-    imgs = DeviceImagePipeline("cpu", out_size=64)([c for c, _ in b2["query_raw"]], [p for _, p in b2["query_raw"]])
+    imgs = images_from_raw_host([c for c, _ in b2["query_raw"]], [p for _, p in b2["query_raw"]])
     assert torch.allclose(imgs, b1["query_images"], atol=1e-6)
     for k in b1["query_targets"]:
         assert torch.equal(b1["query_targets"][k], b2["query_targets"][k]), k
@@ -211,3 +221,43 @@ def test_records_and_episodes_match_reference_classes(tmp_path):
             for k in ("image_id", "height", "width", "num_keypoints", "num_visible_keypoints", "bbox", "bbox_width", "bbox_height", "visibility"):
                 assert x[k] == y[k], k
         assert a["support_metadata"] == b["support_metadata"]
+
+
+class _PlanProbe(torch.utils.data.Dataset):
+    """Each item reports which worker made it and the first numbers of the plan it drew."""
+
+    def __init__(self, tr):
+        self.tr = tr
+
+    def __len__(self):
+        return 8
+
+    def __getitem__(self, i):
+        info = torch.utils.data.get_worker_info()
+        p = self.tr.plan(60, 80)
+        return torch.tensor([-1 if info is None else info.id, i], dtype=torch.float64), torch.from_numpy(np.r_[p.fwd.reshape(-1), float(p.noise_seed)])
+
+
+def test_augmentation_streams_differ_per_worker_rank_and_epoch():
+    """the plan generator is seeded in the process that draws from it, from (seed, rank, torch's per-worker,
+    per-epoch seed).  One generator created in the parent and inherited by every forked worker repeated the same stream in every
+    worker, on every rank, in every epoch."""
+    tr = HostTransform(train=True, size=64, seed=7, rank=0)
+    dl = torch.utils.data.DataLoader(_PlanProbe(tr), batch_size=1, num_workers=2, shuffle=False)
+
+    def epoch():
+        first = {}
+        for who, plan in dl:
+            first.setdefault(int(who[0, 0]), plan[0].clone())
+        return first
+
+    e1, e2 = epoch(), epoch()
+    assert set(e1) == {0, 1}
+    assert not torch.equal(e1[0], e1[1]), "two workers drew the same first plan"
+    assert not torch.equal(e1[0], e2[0]) and not torch.equal(e1[1], e2[1]), "epoch 2 repeated epoch 1's plans"
+    # ranks differ for the same seed and worker seed; the same (seed, rank) in one process is reproducible
+    a, b = HostTransform(train=True, size=64, seed=7, rank=0), HostTransform(train=True, size=64, seed=7, rank=1)
+    a2 = HostTransform(train=True, size=64, seed=7, rank=0)
+    pa, pb, pa2 = a.plan(60, 80), b.plan(60, 80), a2.plan(60, 80)
+    assert pa.noise_seed == pa2.noise_seed and np.array_equal(pa.fwd, pa2.fwd)
+    assert pa.noise_seed != pb.noise_seed

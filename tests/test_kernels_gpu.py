@@ -570,6 +570,61 @@ def test_attention_matrix_core_form_dropout_consistent():
     close(dQ, dQf.cpu(), tol=5e-4, name="dQ"); close(dK, dKf.cpu(), tol=5e-4, name="dK"); close(dV, dVf.cpu(), tol=5e-4, name="dV")
 
 
+@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 72, 128, 2), (1, 64, 200, 0), (2, 224, 224, 1), (1, 33, 97, 1), (2, 200, 40, 0)])
+def test_flash_attention_fwd_bwd(N, Lq, Lk, mode):
+    """csrc/flash_attn.hip (fused Q K^T -> mask -> softmax -> P V on the matrix cores, backward recomputed from the log-sum-exp)
+    against the plain torch expression on the CPU: strided q | k | v views of one (N, L, 768) buffer as the decoder passes
+    them, every mask mode, ragged last blocks."""
+    H = 8
+    big_q, big_k, big_v = rnd(N, Lq, 768, seed=1), rnd(N, Lk, 768, seed=2), rnd(N, Lk, 768, seed=3)
+    q, k, v = big_q[..., :256], big_k[..., 256:512], big_v[..., 512:]
+    qc, kc, vc = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+    mask, kpm = None, None
+    if mode == 1:
+        mask = torch.triu(torch.full((Lq, Lk), float("-inf")), diagonal=1)
+    if mode == 2:
+        kpm = torch.zeros(N, Lk, dtype=torch.bool)
+        kpm[:, 3] = True; kpm[0, 100:] = True
+        mask = torch.zeros(N, 1, 1, Lk).masked_fill(kpm[:, None, None, :], float("-inf"))
+    scale = 32 ** -0.5
+    ref = _attn_ref(qc, kc, vc, scale, mask)
+    go = rnd(N, Lq, 256, seed=4)
+    ref.backward(go)
+    Qd, Kd, Vd = big_q.to(DEV), big_k.to(DEV), big_v.to(DEV)
+    qd, kd, vd = Qd[..., :256], Kd[..., 256:512], Vd[..., 512:]
+    kpm_d = kpm.to(torch.uint8).to(DEV) if kpm is not None else None
+    O, lse = ops.flash_attn_fwd(qd, kd, vd, N, H, Lq, Lk, scale, mask_mode=mode, kpm=kpm_d)
+    close(O, ref, tol=1e-4, name="flash fwd")
+    sref = (qc.detach().view(N, Lq, H, 32).transpose(1, 2) * scale) @ kc.detach().view(N, Lk, H, 32).transpose(1, 2).transpose(-1, -2)
+    if mask is not None:
+        sref = sref + mask
+    close(lse, torch.logsumexp(sref, -1), tol=1e-4, name="flash lse")
+    dQ, dK, dV = torch.zeros_like(Qd), torch.zeros_like(Kd), torch.zeros_like(Vd)
+    ops.flash_attn_bwd(go.to(DEV), qd, kd, vd, O, lse, dQ[..., :256], dK[..., 256:512], dV[..., 512:], N, H, Lq, Lk, scale,
+                       mask_mode=mode, kpm=kpm_d)
+    close(dQ[..., :256], qc.grad, tol=2e-4, name="flash dQ")
+    close(dK[..., 256:512], kc.grad, tol=2e-4, name="flash dK")
+    close(dV[..., 512:], vc.grad, tol=2e-4, name="flash dV")
+    assert float(dQ[..., 256:].abs().sum()) == 0 and float(dK[..., :256].abs().sum()) == 0
+
+
+def test_flash_attention_dropout_matches_the_batched_gemm_form():
+    """Same dropout element index in every attention form: with the same (seed, step, stream) the fused kernel drops exactly the
+    probabilities the batched-GEMM form drops -- outputs and all three gradients agree."""
+    N, H, L = 2, 8, 200
+    q, k, v = rnd(N, L, 256, seed=1).to(DEV), rnd(N, L, 256, seed=2).to(DEV), rnd(N, L, 256, seed=3).to(DEV)
+    g = rnd(N, L, 256, seed=4).to(DEV)
+    rng = ops.RngState(99, DEV)
+    O, P, Pu = ops.attn_mm_fwd(q, k, v, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    Of, lse = ops.flash_attn_fwd(q, k, v, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    close(Of, O.cpu(), tol=3e-4, name="flash dropout vs batched form")
+    dQ, dK, dV = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attn_mm_bwd(g, q, k, v, P, Pu, dQ, dK, dV, N, H, L, L, 0.2, dropout_p=0.3, rng=rng, rng_stream=9)
+    dQf, dKf, dVf = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.flash_attn_bwd(g, q, k, v, Of, lse, dQf, dKf, dVf, N, H, L, L, 0.2, mask_mode=1, dropout_p=0.3, rng=rng, rng_stream=9)
+    close(dQf, dQ.cpu(), tol=5e-4, name="dQ"); close(dKf, dK.cpu(), tol=5e-4, name="dK"); close(dVf, dV.cpu(), tol=5e-4, name="dV")
+
+
 def test_attention_dropout_fwd_bwd_consistent():
     """With dropout the kernel's gradients must be the gradients of its own (masked) forward:
     finite-difference check of sum(O * G) with respect to V (linear in V -> exact up to rounding)."""
@@ -822,6 +877,76 @@ def test_gemm_wgrad_fused_bias_sums(Mo, Ni, Kr, sk, prec):
         ops.set_gemm_precision(old)
     close(out, dy.t() @ x, tol=2e-4, name="tn")
     close(cs, 2.0 + dy.sum(0), tol=2e-4, name="fused bias sums")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("M", [6400, 130])
+def test_gemm_column_limited_residual_and_batched_bias(prec, M):
+    """Round 3 epilogue forms of the decoder's self-attention node: (a) one product over stacked weight rows with a residual of
+    its own leading dimension on the first `res_cols` columns only (q | k | v = tgt [Wq; Wk; Wv]^T, `+ query_pos` on q);
+    (b) a batch of products that read column blocks of one matrix, each with its own weight block and bias block (in_proj)."""
+    C = 256
+    x, w, pos = rnd(M, C, seed=1), rnd(3 * C, C, seed=2, scale=C ** -0.5), rnd(M, C, seed=3)
+    in_w, in_b = rnd(3 * C, C, seed=4, scale=C ** -0.5), rnd(3 * C, seed=5)
+    old = ops.get_gemm_precision()
+    try:
+        ops.set_gemm_precision(prec)
+        xd, wd, pd = x.to(DEV), torch.nn.Parameter(w.to(DEV)), pos.to(DEV)
+        qkv1 = torch.empty(M, 3 * C, device=DEV)
+        ops.gemm(xd, wd, qkv1, M, 3 * C, C, residual=pd, ldr=C, res_cols=C)                    # register-stationary kernel (packed weights)
+        ref1 = x @ w.t()
+        ref1[:, :C] += pos
+        close(qkv1, ref1, tol=1e-4, name="stacked product, residual on the first block")
+        qkv1b = torch.empty(M, 3 * C, device=DEV)
+        ops.gemm(xd, wd.detach()[:, :252].contiguous(), qkv1b, M, 3 * C, 252, lda=C, residual=pd, ldr=C, res_cols=C)   # tiled kernel (K = 252)
+        ref1b = x[:, :252] @ w[:, :252].t()
+        ref1b[:, :C] += pos
+        close(qkv1b, ref1b, tol=1e-4, name="tiled kernel, residual on the first block")
+        qkv2 = torch.empty(M, 3 * C, device=DEV)
+        ops.gemm(qkv1, in_w.to(DEV), qkv2, M, C, C, lda=3 * C, ldb=C, ldc=3 * C, bias=in_b.to(DEV),
+                 batch=(3, 3, 0, C, 0, C * C, 0, C), bias_strides=(0, C))
+        r1 = qkv1.cpu()
+        ref2 = torch.cat([r1[:, i * C:(i + 1) * C] @ in_w[i * C:(i + 1) * C].t() + in_b[i * C:(i + 1) * C] for i in range(3)], 1)
+        close(qkv2, ref2, tol=1e-4, name="batch-3 in_proj with per-block bias")
+        d1 = torch.empty(M, 3 * C, device=DEV)
+        ops.gemm(qkv2, in_w.to(DEV), d1, M, C, C, a_mode=0, b_mode=1, lda=3 * C, ldb=C, ldc=3 * C, batch=(3, 3, 0, C, 0, C * C, 0, C))
+        r2 = qkv2.cpu()
+        close(d1, torch.cat([r2[:, i * C:(i + 1) * C] @ in_w[i * C:(i + 1) * C] for i in range(3)], 1), tol=1e-4, name="batch-3 data gradient")
+    finally:
+        ops.set_gemm_precision(old)
+
+
+def test_decoder_self_attention_node_matches_the_chain_of_nodes():
+    """hip/functional.DecSelfAttnFn against the round-2 composition linear x3 -> mha (same kernels underneath, different
+    grouping): outputs and every gradient, dropout off."""
+    from cape_amd.hip import functional as HF
+    torch.manual_seed(3)
+    N, L, C = 3, 200, 256
+    mk = lambda *s, sc=0.06: torch.nn.Parameter(torch.randn(*s, device=DEV) * sc)
+    wqkv = mk(3 * C, C)
+    wq, wk, wv = (torch.nn.Parameter(wqkv.detach()[i * C:(i + 1) * C]) for i in range(3))      # views of one slab: adjacent, as in the arena
+    in_w, in_b, out_w, out_b = mk(3 * C, C), mk(3 * C, sc=0.1), mk(C, C), mk(C, sc=0.1)
+    tgt = torch.randn(N, L, C, device=DEV, requires_grad=True)
+    pos = torch.randn(N, L, C, device=DEV, requires_grad=True)
+    go = torch.randn(N, L, C, device=DEV)
+    params = [wq, wk, wv, in_w, in_b, out_w, out_b]
+
+    def grads(fn):
+        for t_ in params + [tgt, pos]:
+            t_.grad = None
+        fn().backward(go)
+        HF.Runtime.join()
+        return [t_.grad.clone() for t_ in [tgt, pos] + params]
+
+    def chain():
+        q = HF.linear(tgt, wq, residual=pos)
+        return HF.mha(q, HF.linear(tgt, wk), HF.linear(tgt, wv), in_w, in_b, out_w, out_b, 8, mask_mode=1)
+
+    node = lambda: HF.dec_self_attn(tgt, pos, wq, wk, wv, in_w, in_b, out_w, out_b, 8)
+    with torch.no_grad():
+        close(node(), chain(), tol=1e-4, name="self-attention node forward")
+    for i, (a, b) in enumerate(zip(grads(node), grads(chain))):
+        close(a, b, tol=3e-4, name=f"self-attention node grad {i}")
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])

@@ -53,9 +53,18 @@ def worker(rank, world, port):
         out = model(samples=im, support_coords=sc, support_mask=sm, targets=tg, skeleton_edges=sk)
         (crit(out, tg)["_total"] * scale).backward()
 
+    # step 1 = calibration (use counts are learnt, every bucket goes out in finish()); step 2 = steady state: buckets are launched
+    # from the notifications DURING the backward pass, on the communication stream, while later gradients are still being written
     opt.zero_grad()
     backward(batches[rank], ddp.loss_scale)
     ddp.finish()
+    assert ddp.stats["launched_before_finish"] == 0
+    opt.zero_grad()
+    backward(batches[rank], ddp.loss_scale)
+    ddp.finish()
+    early = ddp.stats["launched_before_finish"]
+    print(f"rank {rank}: steady-state step launched {early} of {len(ddp.buckets)} buckets before finish()", flush=True)
+    assert early >= 1, "no bucket was launched from a notification during the backward pass"
     torch.cuda.synchronize()
     got = [a.grad.clone() for a in opt.arenas]
     # local reference: both ranks' batches accumulated without any exchange
