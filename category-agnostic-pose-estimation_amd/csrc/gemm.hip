@@ -150,9 +150,11 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
                      d->dropout_p == 0.f && (d->a_mode == 0 || d->a_mode == 1) && (d->b_mode == 0 || d->b_mode == 1),
                  "cape_gemm_f32: batched launches take dense modes, no epilogue vector besides the bias, split_k 1, batch <= 65535");
   if (d->mask_src) CAPE_REQUIRE(d->split_k == 1, "cape_gemm_f32: mask_src needs split_k == 1");
-  CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
+  CAPE_REQUIRE(d->precision >= 0 && d->precision <= 2, "cape_gemm_f32: precision must be 0 (fp32), 1 (bf16x3) or 2 (single bf16)");
+  p.single = d->precision == 2;
+  const int prec = d->precision == 0 ? 0 : 1;                       // kernel family: exact fp32 MFMA, or the bf16 split (3 or 1 MFMA per product)
   // register-stationary weights (gemm_rs.hip): dense A against a <= 256-deep weight, the token products of the transformer
-  if (d->precision == 1 && d->batch <= 1 && cape_gemm_rs_eligible(p, d->a_mode, d->b_mode)) return cape_gemm_rs_launch(p, d->b_mode, as_stream(stream));
+  if (prec == 1 && d->batch <= 1 && cape_gemm_rs_eligible(p, d->a_mode, d->b_mode)) return cape_gemm_rs_launch(p, d->b_mode, as_stream(stream));
 
   // vector path: every 16-byte load must be aligned and stay inside its row
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -164,7 +166,6 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   if (d->b_mode == 2 || d->b_mode == 3) vec = vec && (d->N % 4 == 0) && d->N >= 4;
   if (d->batch > 1) vec = vec && ((d->sA0 | d->sA1 | d->sB0 | d->sB1) % 4 == 0);
   if ((d->a_mode >= 2 || d->b_mode >= 2) && !vec) return cape_set_error("cape_gemm_f32: conv modes need the aligned vector path");
-  CAPE_REQUIRE(d->precision == 0 || d->precision == 1, "cape_gemm_f32: precision must be 0 (fp32) or 1 (bf16x3)");
   // skinny products: M <= 64 rows of a dense NT product go to the FMA kernel (exact fp32 in either precision mode)
   if (d->a_mode == 0 && d->b_mode == 0 && d->M <= 64 && d->batch <= 1 && vec && d->split_k == 1 && d->dropout_p == 0.f && !d->colsum_out &&
       !d->mask_src && (d->N + SK_COLS - 1) / SK_COLS < (1 << 30)) {
@@ -185,7 +186,7 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   // but 256x256x43520 split 64, one 128-tile block per CU: 36 -> 40 us, hence the floor on the output size; and
   // 1024x256x6400 split 16 (400 deep per split): 27.7 -> 28.9 us, hence the depth is counted per k-split)
   const long long t128 = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * d->split_k;
-  bool big = d->K / d->split_k >= 1024 && t128 >= 256 && (long long)d->M * d->N >= 256 * 1024 && d->precision == 1 && vec;
+  bool big = d->K / d->split_k >= 1024 && t128 >= 256 && (long long)d->M * d->N >= 256 * 1024 && prec == 1 && vec;
   {
     static const char* force = getenv("CAPE_GEMM_TILE");      // tuning override: 64 or 128
     if (force && force[0] == '1') big = true;
@@ -198,8 +199,8 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   CAPE_REQUIRE(ntiles < (1ll << 31), "cape_gemm_f32: too many tiles");
   CAPE_REQUIRE(ntiles * d->split_k < (1ll << 31), "cape_gemm_f32: grid too large");
   dim3 grid((unsigned)(ntiles * d->split_k), (unsigned)(d->batch > 1 ? d->batch : 1));
-  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream))
-               : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, d->precision, grid, as_stream(stream));
+  int rc = big ? launch_mode<128, 128>(p, d->a_mode, d->b_mode, vec, prec, grid, as_stream(stream))
+               : launch_mode<64, 64>(p, d->a_mode, d->b_mode, vec, prec, grid, as_stream(stream));
   if (rc) return rc;
   CAPE_LAUNCH_CHECK("cape_gemm_f32");
   return 0;

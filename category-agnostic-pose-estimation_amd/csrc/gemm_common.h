@@ -51,6 +51,7 @@ struct GemmP {
   const float* mask_src; long long ldm; float mask_scale;
   // batched launch (grid.y = batch): batch b = b0 * bdiv + b1 offsets the operands by b0 * s?0 + b1 * s?1 elements
   int bdiv; long long sA0, sA1, sB0, sB1, sC0, sC1;
+  int single;                    // bf16x3 kernels only: 1 = one bf16 MFMA per product (hi x hi; precision 2, the measured-only AMP leg)
   int res_cols;                  // 0: residual on every column; else (multiple of 32) on columns < res_cols only
   long long sBias0, sBias1;      // per-batch offsets of `bias`
 };

@@ -29,7 +29,7 @@ struct GroupItem {                                  // 112 bytes
 };
 
 struct GroupArgs {
-  int n;
+  int n, single;
   int bstart[GROUP_MAX + 1];                        // first block of item i (multiples of 8); bstart[n] = grid size
   GroupItem it[GROUP_MAX];
 };
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupArgs g) {
   p.tilesM = q.tilesM; p.tilesN = q.tilesN;
   p.Bpack = nullptr; p.mask_src = nullptr; p.ldm = 0; p.mask_scale = 1.f;
   p.bdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
-  p.res_cols = 0; p.sBias0 = p.sBias1 = 0;
+  p.res_cols = 0; p.sBias0 = p.sBias1 = 0; p.single = g.single;
   gemm_tile_body<BM, BN, 1, BMODE, true, PREC, KFULL>(p, b - g.bstart[i]);
 }
 
@@ -74,17 +74,18 @@ void launch_group(const GroupArgs& g, int prec, bool kfull, hipStream_t s) {
 extern "C" int cape_gemm_group_f32(const cape_gemm_desc* descs, int n, int tile, cape_stream_t stream) {
   CAPE_REQUIRE(descs != nullptr && n >= 1 && n <= GROUP_MAX, "cape_gemm_group_f32: n=%d must be in 1..%d", n, GROUP_MAX);
   CAPE_REQUIRE(tile == 64 || tile == 128, "cape_gemm_group_f32: tile must be 64 or 128");
-  const int b_mode = descs[0].b_mode, prec = descs[0].precision;
+  const int b_mode = descs[0].b_mode, prec_in = descs[0].precision, prec = prec_in == 0 ? 0 : 1;
   CAPE_REQUIRE(b_mode == 1 || b_mode == 3, "cape_gemm_group_f32: only the weight-gradient modes (a_mode 1, b_mode 1 or 3) are grouped");
-  CAPE_REQUIRE(prec == 0 || prec == 1, "cape_gemm_group_f32: precision must be 0 (fp32) or 1 (bf16x3)");
+  CAPE_REQUIRE(prec_in >= 0 && prec_in <= 2, "cape_gemm_group_f32: precision must be 0 (fp32), 1 (bf16x3) or 2 (single bf16)");
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   GroupArgs g;
   g.n = n;
+  g.single = prec_in == 2;
   bool kfull = true;
   long long blocks = 0;
   for (int i = 0; i < n; ++i) {
     const cape_gemm_desc& d = descs[i];
-    CAPE_REQUIRE(d.a_mode == 1 && d.b_mode == b_mode && d.precision == prec, "cape_gemm_group_f32: item %d: mixed modes / precisions", i);
+    CAPE_REQUIRE(d.a_mode == 1 && d.b_mode == b_mode && d.precision == prec_in, "cape_gemm_group_f32: item %d: mixed modes / precisions", i);
     CAPE_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.A && d.B && d.C, "cape_gemm_group_f32: item %d: empty product or null operand", i);
     CAPE_REQUIRE(d.accumulate && !d.scale && !d.bias && !d.residual && !d.relu && d.dropout_p == 0.f && !d.mask_src && d.batch <= 1,
                  "cape_gemm_group_f32: item %d: grouped products accumulate onto C and take no other epilogue operand", i);

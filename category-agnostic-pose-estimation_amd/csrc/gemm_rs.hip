@@ -225,8 +225,10 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
       for (int s = 0; s < KS; ++s) {
         const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(Ah + ao + 16 * s);
         const bf16x8 alo = *reinterpret_cast<const bf16x8*>(Al + ao + 16 * s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[s], acc, 0, 0, 0);
+        if (!p.single) {                                             // uniform; precision 2 keeps hi x hi only
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[s], acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[s], acc, 0, 0, 0);
         if (hh == H1 - 1 && s >= KS - NV && has_next) store_piece(ra[s - (KS - NV)], s - (KS - NV), buf ^ 1);
       }

@@ -415,8 +415,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+          if (!p.single) {                                             // uniform; precision 2 keeps hi x hi only
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
         }
       return;

@@ -164,6 +164,41 @@ def _param_of(p):
     return p._base if (p is not None and isinstance(p._base, torch.nn.Parameter)) else None
 
 
+class _Slot:
+    """Gradient slot of a tensor with several consumers (see `fanout`): the first consumer whose backward produces an exclusively
+    owned data gradient leaves its buffer here; later consumers ADD theirs into it (GEMM `C += ...` epilogue) instead of writing
+    a buffer of their own that a summation pass then reads again."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+_SLOTS = os.environ.get("CAPE_GRAD_SLOTS", "1") == "1"
+
+
+def _slot_of(x):
+    return getattr(x, "_cape_slot", None) if _SLOTS else None
+
+
+def _grad_target(slot, shape, device):
+    """(buffer viewed as `shape`, accumulate?) for a data gradient of `shape` (contiguous)."""
+    if slot is not None and slot.buf is not None:
+        b = slot.buf
+        if b.is_contiguous() and b.numel() == int(torch.Size(shape).numel()) and b.device == device:
+            return b.view(shape), True
+    buf = torch.empty(shape, dtype=torch.float32, device=device)
+    if slot is not None and slot.buf is None:
+        slot.buf = buf
+    return buf, False
+
+
+def _slot_offer(slot, buf):
+    """A non-GEMM producer (LayerNorm backward) offers its freshly written, exclusively owned gradient buffer."""
+    if slot is not None and slot.buf is None and buf is not None and buf.is_contiguous():
+        slot.buf = buf
+
+
 class _Side:
     """with _Side(tensors...): kernels launched inside go to the side stream, ordered after the current stream's work so far
     (one C call: event record + wait; no framework stream switch); the listed tensors are kept alive until the next join --
@@ -221,6 +256,7 @@ class LinearFn(torch.autograd.Function):
                  rng=rng, rng_stream=rng_stream)
         ctx.save_for_backward(x2, weight, y if (relu or dropout_p > 0) else None)
         ctx.w_ref, ctx.b_ref = weight, bias
+        ctx.slot = _slot_of(x)
         ctx.meta = (relu, dropout_p, bias is not None, residual is not None, x.shape, M, N, K)
         return y.view(*x.shape[:-1], N)
 
@@ -235,8 +271,8 @@ class LinearFn(torch.autograd.Function):
             dpre = ops.relu_drop_bwd(dy2, y, 1.0 / (1.0 - p) if p > 0 else 1.0)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-            ops.gemm(dpre, weight, dx, M, K, N, a_mode=0, b_mode=1, ldb=weight.stride(0))
+            dx, acc = _grad_target(ctx.slot, (M, K), dy.device)
+            ops.gemm(dpre, weight, dx, M, K, N, a_mode=0, b_mode=1, ldb=weight.stride(0), accumulate=acc)
             dx = dx.view(xshape)
         wsink, bsink = _sink(ctx.w_ref), _sink(ctx.b_ref)
         need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
@@ -283,6 +319,7 @@ class FFNFn(torch.autograd.Function):
         ops.gemm(h, w2, y, M, N, Hd, ldb=w2.stride(0), bias=b2)
         ctx.save_for_backward(x2, w1, w2, h)
         ctx.refs = (w1, b1, w2, b2)
+        ctx.slot = _slot_of(x)
         ctx.meta = (dropout_p, x.shape, M, K, Hd, N)
         return y.view(*x.shape[:-1], N)
 
@@ -296,8 +333,8 @@ class FFNFn(torch.autograd.Function):
         ops.gemm(dy2, w2, dpre, M, Hd, N, a_mode=0, b_mode=1, ldb=w2.stride(0), mask_src=h, mask_scale=1.0 / (1.0 - p) if p > 0 else 1.0)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-            ops.gemm(dpre, w1, dx, M, K, Hd, a_mode=0, b_mode=1, ldb=w1.stride(0))
+            dx, acc = _grad_target(ctx.slot, (M, K), dy.device)
+            ops.gemm(dpre, w1, dx, M, K, Hd, a_mode=0, b_mode=1, ldb=w1.stride(0), accumulate=acc)
             dx = dx.view(xshape)
         sinks = [_sink(t) for t in ctx.refs]
         if all(k is not None for k in sinks) and all(ctx.needs_input_grad[1:5]):
@@ -600,6 +637,7 @@ class AddLayerNormFn(torch.autograd.Function):
                                                          rng_stream=rng_stream)
         ctx.save_for_backward(x, y, gamma, mean, rstd)
         ctx.refs = (gamma, beta)
+        ctx.slot = _slot_of(x)
         ctx.meta = (dropout_p, rng_stream, pos is not None)
         ctx.set_materialize_grads(False)        # an unused output arrives as None, not as a zero-filled tensor
         if pos is None:
@@ -624,6 +662,8 @@ class AddLayerNormFn(torch.autograd.Function):
         rng = Runtime.get_rng(x.device) if p > 0 else None
         dx, dy = ops.add_layernorm_bwd(d_out, d_out_pos, x, y, gamma, mean, rstd, dg, db, dropout_p=p, rng=rng,
                                        rng_stream=stream)
+        if y is None or dy is not dx:               # (without dropout the kernel hands ONE buffer to x and y: not exclusively x's)
+            _slot_offer(ctx.slot, dx)
         if direct:
             Runtime.notify(_param_of(ctx.refs[0]), _param_of(ctx.refs[1]))
             dg = db = None
@@ -662,7 +702,11 @@ class FanOutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        gs = [_c(g) for g in grads if g is not None]
+        gs, seen = [], set()
+        for g in grads:                                      # consumers that accumulated into the slot's buffer report it more than once
+            if g is not None and (g.data_ptr(), g.numel()) not in seen:
+                seen.add((g.data_ptr(), g.numel()))
+                gs.append(_c(g))
         if not gs:
             return None, None
         out = gs[0]
@@ -675,7 +719,11 @@ def fanout(x, k):
     """k aliases of x whose gradients are summed by one HIP launch (no-op outside autograd or for k == 1)."""
     if k == 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * k
-    return FanOutFn.apply(x, k)
+    outs = FanOutFn.apply(x, k)
+    slot = _Slot()
+    for o in outs:
+        o._cape_slot = slot                                  # consumers find the shared gradient slot on their input (see _Slot)
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------
@@ -855,6 +903,7 @@ class MHAFn(torch.autograd.Function):
         ops.gemm(O.view(-1, C), out_w, out, N * Lq, C, C, bias=out_b)
         ctx.save_for_backward(q_in, k_in, v_in, in_w, out_w, q, k, v, O, lse, kpm_u8)
         ctx.refs = (in_w, in_b, out_w, out_b)
+        ctx.slot_q = _slot_of(q_in)
         ctx.meta = (nheads, mask_mode, dropout_p, rng_stream, scale, k_in is v_in, q_in is k_in, mm, merged)
         return out
 
@@ -941,8 +990,8 @@ class MHAFn(torch.autograd.Function):
                 if not need_k:
                     dv_in, dk_in = dk_in, None
             if need_q:
-                dq_in = torch.empty(N, Lq, C, dtype=torch.float32, device=dev)
-                ops.gemm(dq.view(-1, C), in_w, dq_in, Mq, C, C, a_mode=0, b_mode=1)
+                dq_in, acc = _grad_target(ctx.slot_q, (N, Lq, C), dev)
+                ops.gemm(dq.view(-1, C), in_w, dq_in, Mq, C, C, a_mode=0, b_mode=1, accumulate=acc)
             return dq_in, dk_in, dv_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None, None
         if need_k:
             dk_in = torch.empty(N, Lk, C, dtype=torch.float32, device=dev)
@@ -1008,6 +1057,7 @@ class DecSelfAttnFn(torch.autograd.Function):
         ctx.refs = (wq, wk, wv, in_w, in_b, out_w, out_b)
         ctx.meta = (nheads, dropout_p, rng_stream, scale, mm, stacked, N, L, C)
         ctx.flash = flash
+        ctx.slot = _slot_of(tgt)
         return out
 
     @staticmethod
@@ -1042,12 +1092,12 @@ class DecSelfAttnFn(torch.autograd.Function):
         need_x, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = None
         if need_x:
-            dx = torch.empty(N, L, C, dtype=torch.float32, device=dev)
+            dx, acc = _grad_target(ctx.slot, (N, L, C), dev)
             if stacked:
-                ops.gemm(dqkv1, torch.as_strided(wq, (3 * C, C), (C, 1)), dx, M, C, 3 * C, a_mode=0, b_mode=1)
+                ops.gemm(dqkv1, torch.as_strided(wq, (3 * C, C), (C, 1)), dx, M, C, 3 * C, a_mode=0, b_mode=1, accumulate=acc)
             else:
                 for i, w in enumerate((wq, wk, wv)):
-                    ops.gemm(dqkv1[:, i * C:], w, dx, M, C, C, a_mode=0, b_mode=1, lda=3 * C, accumulate=i > 0)
+                    ops.gemm(dqkv1[:, i * C:], w, dx, M, C, C, a_mode=0, b_mode=1, lda=3 * C, accumulate=acc or i > 0)
 
         def wgrads():
             Mv = dqkv2.view(M, 3 * C)

@@ -68,7 +68,8 @@ def train_one_epoch_episodic(model: torch.nn.Module, criterion: torch.nn.Module,
     bf16x3 split by default (CAPE_GEMM_PRECISION=f32 selects exact fp32 MFMA); plain fp16/bf16 autocast misses the parity
     bar of 1e-3 on logits."""
     if scaler is not None:
-        raise ValueError("AMP is not available on the MI355X path (fp32 MFMA); run without --use_amp")
+        raise ValueError("a GradScaler has no role on the MI355X path: --use_amp selects bf16 MFMA products with fp32 accumulation "
+                         "(run_training), which need no loss scaling")
     model.train()
     criterion.train()
     if hasattr(optimizer, "max_norm"):
@@ -324,6 +325,14 @@ def run_training(args):
                                              num_workers=args.num_workers, pin_memory=True)
     optimizer = ArenaAdamW(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay,
                            max_norm=args.clip_max_norm)
+    if getattr(args, "use_amp", False):
+        # the reference's --use_amp = torch.cuda.amp.autocast + GradScaler (engine_cape.py:164-179).  Its MI355X counterpart: every GEMM
+        # as ONE bf16 MFMA per product (fp32 master weights, fp32 accumulation, fp32 everything else; bf16 has fp32's exponent range,
+        # so no loss scaling).  A throughput option, NOT the parity path: logits deviate ~2e-2 from the fp32 reference.
+        from ..hip import ops as _ops
+        _ops.set_gemm_precision("bf16")
+        if utils.is_main_process():
+            print("--use_amp: GEMMs as single bf16 MFMA products (fp32 accumulate); outside the 1e-3 parity tolerance by design")
     ddp = EpisodeDataParallel(model, optimizer) if world > 1 else None
     lr_scheduler = build_scheduler(optimizer, args, steps_per_epoch=len(train_loader))
     best_pck, no_improve = 0.0, 0

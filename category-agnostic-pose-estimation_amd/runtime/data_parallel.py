@@ -95,6 +95,11 @@ class EpisodeDataParallel:
         bi = self._bucket_of.get(id(p))
         if bi is None or not self.sync_enabled:
             return
+        self._tick(p, bi)
+
+    def _tick(self, p, bi):
+        """One more gradient contribution of `p` has been enqueued (a direct-to-arena launch, or autograd's accumulation: a
+        parameter may receive both kinds, in either order -- every contribution counts once)."""
         self._count[id(p)] = self._count.get(id(p), 0) + 1
         if not self._calibrated:
             return                                  # calibration step: count uses, buckets go in finish()
@@ -132,9 +137,7 @@ class EpisodeDataParallel:
             if key in self._seen:
                 return                              # autograd accumulates a parameter's gradient once per backward
             self._seen.add(key)
-            self._count[id(_p)] = 1
-            if self._calibrated and self._uses.get(id(_p)) == 1:
-                self._param_done(bi)
+            self._tick(_p, bi)
         return hook
 
     def _launch(self, bi):

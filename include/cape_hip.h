@@ -81,7 +81,9 @@ typedef struct {
                               is the bias gradient of the nn.Linear whose wgrad this GEMM is (atomically accumulated once per
                               k-split; the caller provides the value to accumulate onto) */
   int precision;           /* 0 = exact fp32 MFMA; 1 = bf16x3 split (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32
-                              accumulate, ~2^-16 relative per product); odd/unaligned shapes always use 0 */
+                              accumulate, ~2^-16 relative per product); 2 = one bf16 MFMA per product (hi*hi: what
+                              torch.autocast(bfloat16) computes -- the measured-only mixed-precision leg of `--use_amp`,
+                              engine_cape.py:164-179; misses the 1e-3 logit bar); odd/unaligned shapes always use 0 */
   /* optional (precision 1): the B operand as fragment-ordered bf16 (hi, lo) planes written by cape_pack_weights for this
      (N, K, ldb, b_mode).  Only the register-stationary kernel (dense A, K in {64, 128, 256}) reads it: its per-block weight
      prologue becomes K/8 coalesced loads per wave instead of a load -> split -> LDS -> fragment pass; every other shape

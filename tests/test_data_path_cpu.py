@@ -24,7 +24,8 @@ needs_ref = pytest.mark.skipif(not refshim.reference_available(), reason="refere
 CATS = {1: 5, 2: 9, 3: 4}
 
 
-def make_dataset(root, n_per_cat=5, seed=0):
+def make_dataset(root, n_per_cat=5, seed=0, scale=1):
+    """`scale` multiplies the image sizes (bench.py's loader benchmark uses MP-100-like sizes: scale 4 = 240-560 x 200-480)."""
     from PIL import Image
     rng = np.random.default_rng(seed)
     os.makedirs(root / "data", exist_ok=True)
@@ -32,7 +33,7 @@ def make_dataset(root, n_per_cat=5, seed=0):
     img_id = 100
     for cat, nk in CATS.items():
         for j in range(n_per_cat):
-            w, h = int(rng.integers(60, 140)), int(rng.integers(50, 120))
+            w, h = int(rng.integers(60, 140)) * scale, int(rng.integers(50, 120)) * scale
             arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
             name = f"c{cat}/img_{img_id}.png"
             os.makedirs(root / "data" / f"c{cat}", exist_ok=True)

@@ -1014,6 +1014,41 @@ def test_gemm_group_conv_wgrads():
         close(dw, ref, tol=2e-4, name=f"conv wgrad group item {i}")
 
 
+def test_gradient_slots_match_summation_pass(monkeypatch):
+    """hip/functional._Slot: consumers of a multiply-used tensor add their data gradients into ONE buffer (GEMM accumulate
+    epilogue) instead of a summation pass over separate buffers.  A post-norm block with dropout (the LayerNorm backward offers
+    the first buffer, the FFN / Linear data gradients accumulate into it) and a 3-consumer fan-out, slots on == slots off."""
+    from cape_amd.hip import functional as HF
+    torch.manual_seed(1)
+    C = 256
+    mk = lambda *s, sc=0.06: torch.nn.Parameter(torch.randn(*s, device=DEV) * sc)
+    w1, b1, w2, b2, wv, bv = mk(1024, C), mk(1024, sc=0.1), mk(C, 1024, sc=0.03), mk(C, sc=0.1), mk(C, C), mk(C, sc=0.1)
+    g1, be1 = torch.nn.Parameter(torch.ones(C, device=DEV)), torch.nn.Parameter(torch.zeros(C, device=DEV))
+    x0 = torch.randn(3, 200, C, device=DEV)
+    go = torch.randn(3, 200, C, device=DEV)
+    params = [w1, b1, w2, b2, wv, bv, g1, be1]
+    HF.Runtime.seed(77, torch.device(DEV))
+
+    def run(slots):
+        monkeypatch.setattr(HF, "_SLOTS", slots)
+        x = x0.clone().requires_grad_(True)
+        for p_ in params:
+            p_.grad = None
+        a, b, c = HF.fanout(x, 3)                                            # value-projection-like consumer + FFN + residual path
+        v = HF.linear(a, wv, bv)
+        h = HF.ffn(b, w1, b1, w2, b2, dropout_p=0.1, rng_stream=5)
+        y = HF.add_layernorm(c, h, g1, be1, dropout_p=0.1, rng_stream=6)     # backward runs first: offers its dx
+        (y + v).backward(go)
+        HF.Runtime.join()
+        return [x.grad.clone()] + [p_.grad.clone() for p_ in params]
+
+    ref = run(False)
+    got = run(True)
+    for i, (a_, b_) in enumerate(zip(got, ref)):
+        close(a_, b_, tol=2e-4, name=f"slot grad {i}")
+        assert float(b_.abs().max()) > 0
+
+
 def test_deferred_weight_gradients_match_immediate_launches():
     """hip/functional.Runtime.defer_wgrad: a backward pass whose weight gradients are queued and launched in groups produces the
     gradients of the same pass with one launch per product (a stack of Linear / FFN nodes writing straight into arena-style

@@ -14,7 +14,7 @@ def collect(d, counter):
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         with open(path) as f:
             for r in csv.DictReader(f):
-                if ("gemm_kernel" in r["Kernel_Name"] or "gemm_rs_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                if any(k in r["Kernel_Name"] for k in ("gemm_kernel", "gemm_rs_kernel", "gemm_group_kernel")) and r["Counter_Name"] == counter:
                     tot += float(r["Counter_Value"])
                     n += 1
     return tot, n
@@ -23,7 +23,10 @@ def collect(d, counter):
 def main():
     fetch_kib, nf = collect(sys.argv[1], "FETCH_SIZE")
     write_kib, nw = collect(sys.argv[2], "WRITE_SIZE")
-    out = {"kernel": "gemm_kernel<...> + gemm_rs_kernel<...> (all instantiations)", "launches_fetch_pass": nf, "launches_write_pass": nw,
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_tree_hash
+    out = {"kernel": "gemm_kernel<...> + gemm_rs_kernel<...> + gemm_group_kernel<...> (all instantiations)", "csrc_hash": csrc_tree_hash(), "launches_fetch_pass": nf, "launches_write_pass": nw,
            "fetch_bytes_per_launch": 2.0 * fetch_kib * 1024 / max(nf, 1), "write_bytes_per_launch": write_kib * 1024 / max(nw, 1),
            "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads), WRITE_SIZE x1; KiB -> bytes"}
     out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
