@@ -33,7 +33,7 @@ class Runtime:
     # (csrc/gemm_group.hip) -- and whatever is left when the autograd engine finishes the pass.  Round 2 paid 199 launches,
     # 24-64 k-splits each to fill the chip alone, for what is now ~15 launches of 4-8 k-splits.
     defer_wgrad = os.environ.get("CAPE_DEFER_WGRAD", "1") == "1"
-    wgrad_group = int(os.environ.get("CAPE_WGRAD_GROUP", "24"))
+    wgrad_group = int(os.environ.get("CAPE_WGRAD_GROUP", "12"))
     wq = {}                      # (tile, b_mode, precision) -> [(desc, keep, shape)]
     wq_total = 0
     wq_notify = []               # parameters whose notification (data-parallel bucket bookkeeping) waits for the queued products
@@ -597,11 +597,38 @@ class BottleneckFn(torch.autograd.Function):
             idt = ConvFn.forward(cd, x, wd, sd, bd, None, stride, 0, False, allow_split)
         c3 = _PlainCtx((True, w3.requires_grad, False, False, nx or wd is not None))
         y = ConvFn.forward(c3, o2, w3, s3, b3, idt, 1, 0, True, allow_split)
+        # every tensor the four stages keep goes through the node's own save_for_backward: the block output `y` is among them
+        # (conv3's ReLU mask), and an output held as a plain attribute of the context is a reference cycle through its grad_fn
+        # that Python's collector cannot see -- round 2 leaked ~1.4 GiB of trunk activations per training step that way
+        flat, spans = [], []
+        for c in (c1, c2, c3, cd):
+            if c is None:
+                spans.append(None)
+                continue
+            spans.append((len(flat), len(c.saved_tensors)))
+            flat.extend(c.saved_tensors)
+            c.saved_tensors = ()
+        ctx.save_for_backward(*flat)
         ctx.sub = (c1, c2, c3, cd)
+        ctx.spans = spans
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        c1, c2, c3, cd = ctx.sub
+        saved = ctx.saved_tensors
+        for c, sp in zip(ctx.sub, ctx.spans):
+            if c is not None:
+                c.saved_tensors = tuple(saved[sp[0]:sp[0] + sp[1]])
+        try:
+            return BottleneckFn._backward(ctx, dy)
+        finally:
+            for c in ctx.sub:                           # nothing of this pass stays on the long-lived stage contexts
+                if c is not None:
+                    c.saved_tensors, c.accum_dx = (), None
+
+    @staticmethod
+    def _backward(ctx, dy):
         c1, c2, c3, cd = ctx.sub
         d2, dw3, _, _, dres = ConvFn.backward(c3, dy)[:5]
         d1, dw2 = ConvFn.backward(c2, d2)[:2]

@@ -70,6 +70,31 @@ def main():
     cnt = collections.Counter((s, n) for s, _, n in new)
     for (shape, nbytes), k in sorted(cnt.items(), key=lambda kv: -kv[0][1] * kv[1])[:25]:
         print(f"  x{k}  shape {shape}  storage {nbytes / 2**20:.1f} MiB")
+    # who holds one of them?
+    import types
+    victims = [o for o in gc.get_objects() if isinstance(o, torch.Tensor) and o.is_cuda and id(o) in b and id(o) not in a and id(o) in c
+               and tuple(o.shape) == (32, 32, 32, 512)][:2]
+    for v in victims:
+        print("victim", tuple(v.shape), "refcount", sys.getrefcount(v))
+        for r in gc.get_referrers(v):
+            if r is victims or isinstance(r, types.FrameType):
+                continue
+            desc = type(r).__name__
+            if isinstance(r, dict):
+                desc += " keys=" + str(list(r.keys())[:8])
+            elif isinstance(r, (list, tuple)):
+                desc += f" len={len(r)} types={[type(x).__name__ for x in r[:6]]}"
+            print("   referrer:", desc)
+            for r2 in gc.get_referrers(r)[:6]:
+                if isinstance(r2, types.FrameType) or r2 is victims:
+                    continue
+                d2 = type(r2).__name__
+                if isinstance(r2, dict):
+                    d2 += " keys=" + str(list(r2.keys())[:8])
+                elif isinstance(r2, (list, tuple)):
+                    d2 += f" len={len(r2)}"
+                print("        <-", d2)
+    del victims
     for i in range(6, 10):
         step(i)
     torch.cuda.synchronize()
