@@ -44,6 +44,25 @@ __global__ void add_n_kernel(const AddNP p, float* o, long long n) {
   }
 }
 
+// the same with row-strided sources: source j is (rows, cols) with row stride ld[j] (a column block of a wider buffer, e.g. the
+// q part of the decoder's wide [dq | dk | dv] gradient), cols % 4 == 0
+struct AddNRowsP { const float* src[8]; long long ld[8]; int k; };
+__global__ void add_n_rows_kernel(const AddNRowsP p, float* o, long long rows, int cols) {
+  const int c4 = cols >> 2;
+  GSTRIDE(i, rows * c4) {
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    float4 s = *reinterpret_cast<const float4*>(p.src[0] + r * p.ld[0] + c);
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+      if (j < p.k) {
+        const float4 y = *reinterpret_cast<const float4*>(p.src[j] + r * p.ld[j] + c);
+        s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+      }
+    *reinterpret_cast<float4*>(o + r * cols + c) = s;
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* x, float* o, int N, int C, int H, int W, int Cp) {
   const long long tot = (long long)N * H * W * Cp;
   GSTRIDE(i, tot) {
@@ -375,6 +394,25 @@ extern "C" int cape_add_n_f32(const float* const* srcs, int k, float* out, long 
   p.k = k;
   LAUNCH1(add_n_kernel, n / 4 + 1, 1, p, out, n);
   CAPE_LAUNCH_CHECK("cape_add_n_f32");
+  return 0;
+}
+
+extern "C" int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long rows, int cols,
+                                   cape_stream_t stream) {
+  CAPE_REQUIRE(srcs && lds && out && k >= 1 && k <= 8 && rows >= 0 && cols >= 4 && cols % 4 == 0, "cape_add_n_rows_f32: 1..8 sources, cols % 4 == 0");
+  if (rows == 0) return 0;
+  AddNRowsP p;
+  uintptr_t al = reinterpret_cast<uintptr_t>(out);
+  for (int j = 0; j < 8; ++j) {
+    p.src[j] = j < k ? srcs[j] : srcs[0];
+    p.ld[j] = j < k ? lds[j] : lds[0];
+    CAPE_REQUIRE(p.src[j] != nullptr && p.ld[j] >= cols && p.ld[j] % 4 == 0, "cape_add_n_rows_f32: null source or bad row stride");
+    al |= reinterpret_cast<uintptr_t>(p.src[j]);
+  }
+  CAPE_REQUIRE((al & 15) == 0, "cape_add_n_rows_f32: pointers must be 16-byte aligned");
+  p.k = k;
+  LAUNCH1(add_n_rows_kernel, rows * (cols / 4), 1, p, out, rows, cols);
+  CAPE_LAUNCH_CHECK("cape_add_n_rows_f32");
   return 0;
 }
 

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmP p) {
   const int n = n0 + col;
   if (row < p.M && n < p.N) {
     float v = acc * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
-    if (p.residual) v += p.residual[(long long)row * p.ldr + n];
+    if (p.residual && (p.res_cols == 0 || n < p.res_cols)) v += p.residual[(long long)row * p.ldr + n];
     if (p.relu) v = fmaxf(v, 0.f);
     float* cp = p.C + (long long)row * p.ldc + n;
     if (p.accumulate) v += *cp;

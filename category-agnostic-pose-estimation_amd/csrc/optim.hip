@@ -6,8 +6,11 @@
 
 namespace {
 
-// (at most 256 blocks of 16 waves: every block ends in ONE atomic add to the same address; with 2048 small blocks that
-// serialised chain was two thirds of the kernel)
+// Sum of squares as per-block PARTIAL sums: exactly SUMSQ_PARTS blocks of 16 waves, block b writes out[b] (blocks beyond the data
+// write 0).  No float atomics: a reduction whose order depends on block arrival gave two data-parallel replicas -- same all-reduced
+// gradient -- clip coefficients one ulp apart, and their parameters drifted from each other step by step (tools/ddp_rehearsal.py).
+// The consumer (adamw_kernel) adds the partials in a fixed order.
+constexpr int SUMSQ_PARTS = CAPE_SUMSQ_PARTS;
 __global__ void __launch_bounds__(1024) sumsq_kernel(const float* g, long long n, float* out) {
   __shared__ float sh[16];
   float s = 0.f;
@@ -24,16 +27,27 @@ __global__ void __launch_bounds__(1024) sumsq_kernel(const float* g, long long n
     float a = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) a += sh[k];
-    atomicAdd(out, a);
+    out[blockIdx.x] = a;
   }
 }
 
 __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
                                                      float b1, float b2, float eps, float wd, float max_norm,
-                                                     const float* sumsq, const int64_t* step_count, const float* lr_dev) {
+                                                     const float* sumsq, int n_parts, const int64_t* step_count, const float* lr_dev) {
   if (lr_dev) lr = lr_dev[0];                                // the schedule's value of this step, kept on the device (replayed graphs)
   float coef = 1.f;
-  if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
+  if (max_norm > 0.f) {
+    // global gradient norm from the partial sums, the same fixed order in every block (and on every rank)
+    __shared__ float tot;
+    if (threadIdx.x < 64) {
+      float a = 0.f;
+      for (int k = threadIdx.x; k < n_parts; k += 64) a += sumsq[k];
+      a = wave_sum(a);
+      if (threadIdx.x == 0) tot = a;
+    }
+    __syncthreads();
+    coef = fminf(1.f, max_norm / (sqrtf(tot) + 1e-6f));
+  }
   const float t = (float)step_count[0];
   const float bc1 = 1.f - powf(b1, t);
   const float bc2s = sqrtf(1.f - powf(b2, t));
@@ -59,24 +73,21 @@ extern "C" int cape_sumsq(const float* g, long long n, float* out, cape_stream_t
   CAPE_REQUIRE(g && out && n >= 0, "cape_sumsq: bad arguments");
   if (n == 0) return 0;
   CAPE_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, "cape_sumsq: g must be 16-byte aligned");
-  long long b = (n / 4 + 1023) / 1024;
-  if (b > 256) b = 256;
-  if (b < 1) b = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)b), dim3(1024), 0, as_stream(stream), g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_PARTS), dim3(1024), 0, as_stream(stream), g, n, out);
   CAPE_LAUNCH_CHECK("cape_sumsq");
   return 0;
 }
 
 extern "C" int cape_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, float max_norm, const float* sumsq, const int64_t* step_count,
-                               const float* lr_dev, cape_stream_t stream) {
+                               float eps, float weight_decay, float max_norm, const float* sumsq, int n_parts,
+                               const int64_t* step_count, const float* lr_dev, cape_stream_t stream) {
   CAPE_REQUIRE(p && g && m && v && step_count && n >= 0, "cape_adamw_step: bad arguments");
-  CAPE_REQUIRE(max_norm <= 0.f || sumsq, "cape_adamw_step: clipping needs sumsq");
+  CAPE_REQUIRE(max_norm <= 0.f || (sumsq && n_parts >= 1), "cape_adamw_step: clipping needs the partial sums of cape_sumsq");
   if (n == 0) return 0;
   long long b = (n + 255) / 256;
   if (b > 4096) b = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)b), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, max_norm, sumsq, step_count, lr_dev);
+                     weight_decay, max_norm, sumsq, n_parts, step_count, lr_dev);
   CAPE_LAUNCH_CHECK("cape_adamw_step");
   return 0;
 }

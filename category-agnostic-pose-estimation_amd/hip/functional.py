@@ -27,6 +27,7 @@ class Runtime:
     capture_keep = None          # list while a hipGraph capture is in progress (runtime/graph_step.py)
 
     pending = []                 # tensors read by enqueued side-stream kernels: kept alive until join()
+    side_dirty = False           # work has been forked onto the side stream since the last join
 
     # Weight gradients are not launched where the backward pass produces them: nothing waits for one until the optimizer
     # step, so their GEMM descriptors are queued (per tile class) and submitted `wgrad_group` at a time as ONE grouped launch
@@ -50,7 +51,8 @@ class Runtime:
     def join(cls):
         """Make the current stream wait for all enqueued side-stream work (call before the optimizer step)."""
         cls.flush_wgrads()
-        if cls.side is not None:
+        if cls.side is not None and cls.side_dirty:     # (nothing forked since the last join: no event to wait for -- a capture that
+            cls.side_dirty = False                      #  only holds the optimizer step must not touch the un-captured side stream)
             lib.call("cape_stream_join", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(cls.side_raw))
             if cls.capture_keep is None:
                 cls.pending.clear()
@@ -102,6 +104,7 @@ class Runtime:
         if side:                                        # ordered after everything the main stream has been given so far
             cls.side_stream()
             lib.call("cape_stream_fork", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(cls.side_raw))
+            cls.side_dirty = True
             ops._stream_override[0] = cls.side_raw
         try:
             for i in range(0, len(items), lib.GEMM_GROUP_MAX):
@@ -133,6 +136,13 @@ class Runtime:
     @classmethod
     def seed(cls, seed, device):
         cls.rng = ops.RngState(int(seed), device)
+
+
+def _mark_side_dirty():
+    Runtime.side_dirty = True
+
+
+ops._on_fork[0] = _mark_side_dirty
 
 
 def capturing():
@@ -220,6 +230,7 @@ class _Side:
             ops._lazy_fork[0] = True                    # queued products need no fork here; any other launch orders the stream first
         else:
             lib.call("cape_stream_fork", ctypes.c_void_p(ops.raw_current_stream()), ctypes.c_void_p(Runtime.side_raw))
+            Runtime.side_dirty = True
         return self
 
     def _sink(self, desc, keep, shape):
@@ -733,13 +744,23 @@ class FanOutFn(torch.autograd.Function):
         for g in grads:                                      # consumers that accumulated into the slot's buffer report it more than once
             if g is not None and (g.data_ptr(), g.numel()) not in seen:
                 seen.add((g.data_ptr(), g.numel()))
-                gs.append(_c(g))
+                gs.append(g)
         if not gs:
             return None, None
+        if len(gs) > 1 and len(gs) <= 8 and not all(g.is_contiguous() for g in gs) and all(_row_strided(g) for g in gs):
+            return ops.add_n_rows(gs), None                  # a summand is a column block of a wider buffer: summed where it lies
+        gs = [_c(g) for g in gs]
         out = gs[0]
         for i in range(0, len(gs) - 1, 7):                  # 8 sources per launch
             out = ops.add_n([out] + gs[1 + i:8 + i]) if len(gs) > 1 else out
         return out, None
+
+
+def _row_strided(g):
+    if g.dim() < 2 or g.stride(-1) != 1 or g.shape[-1] % 4 or g.data_ptr() % 16 or g.stride(-2) % 4:
+        return False
+    st, sh = g.stride(), g.shape
+    return all(st[i] == st[i + 1] * sh[i + 1] for i in range(len(sh) - 2))
 
 
 def fanout(x, k):

@@ -89,6 +89,7 @@ class AugItem(ctypes.Structure):
 
 DECODE_MAX_LAYERS = 8
 GEMM_GROUP_MAX = 32          # CAPE_GEMM_GROUP_MAX
+SUMSQ_PARTS = 256            # CAPE_SUMSQ_PARTS
 
 
 class DecodeLayerDesc(ctypes.Structure):
@@ -141,6 +142,7 @@ _SIGS = {
     "cape_add_f32": [P, P, P, LL, P],
     "cape_level_embed_add": [P, P, P, P, I, I, I, I, P],
     "cape_add_n_f32": [POINTER(c_void_p), I, P, LL, P],
+    "cape_add_n_rows_f32": [POINTER(c_void_p), POINTER(c_longlong), I, P, LL, I, P],
     "cape_augment_batch": [P, I, I, I, P, P, P],
     "cape_gelu_f32": [P, P, LL, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],
@@ -169,7 +171,7 @@ _SIGS = {
     "cape_zero_rows": [P, P, LL, I, P],
     "cape_loss_fwd_bwd": [P, P, P, P, P, P, F, F, F, P, P, P, P, I, LL, P],
     "cape_sumsq": [P, LL, P, P],
-    "cape_adamw_step": [P, P, P, P, LL, F, F, F, F, F, F, P, P, P, P],
+    "cape_adamw_step": [P, P, P, P, LL, F, F, F, F, F, F, P, I, P, P, P],
     "cape_step_increment": [P, P],
     "cape_decode_next_tokens": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cape_decode_advance": [P, LL, P, LL, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P, P],

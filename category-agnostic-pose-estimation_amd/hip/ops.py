@@ -22,6 +22,7 @@ _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 _stream_override = [None]        # set by hip/functional._Side: launches go to the weight-gradient side stream
 _lazy_fork = [False]             # the side stream has not yet been ordered after the main stream for the current _Side block
+_on_fork = [None]                # callback of hip/functional.Runtime: the side stream now holds work that a join must wait for
 _wgrad_sink = [None]             # callable(desc, keep, shape) while weight-gradient products are being queued (Runtime.defer_wgrad)
 
 
@@ -39,6 +40,8 @@ def _stream():
         if _lazy_fork[0]:           # first launch of a _Side block that queues its weight gradients: order the side stream now
             _lazy_fork[0] = False
             lib.call("cape_stream_fork", ctypes.c_void_p(raw_current_stream()), ctypes.c_void_p(_stream_override[0]))
+            if _on_fork[0] is not None:
+                _on_fork[0]()
         return ctypes.c_void_p(_stream_override[0])
     if _raw_stream is not None and _raw_device is not None:
         return ctypes.c_void_p(_raw_stream(_raw_device()))
@@ -666,6 +669,34 @@ def augment_batch(items_dev_u8, n, max_pixels, out_size, mean=None, std=None):
     lib.call("cape_augment_batch", _p(items_dev_u8), n, int(max_pixels), int(out_size), _p(mean), _p(std), _stream())
 
 
+def add_n_rows(tensors):
+    """Sum of 1..8 tensors of one shape whose last dimension is dense and whose leading dimensions collapse to one row index
+    with a uniform row stride (contiguous tensors, or column blocks of wider contiguous buffers): one pass, no copies."""
+    k = len(tensors)
+    assert 1 <= k <= 8
+    shape = tensors[0].shape
+    cols = shape[-1]
+    rows = tensors[0].numel() // cols
+    lds = []
+    for t in tensors:
+        _chk(t, "add_n_rows.src", contiguous=False)
+        assert t.shape == shape and t.stride(-1) == 1 and cols % 4 == 0
+        v = t.reshape(rows, cols) if t.is_contiguous() else t
+        if not t.is_contiguous():
+            # leading dims must walk one uniform row stride: (d0, d1, ..., cols) with stride[i] == stride[i+1] * shape[i+1]
+            st, sh = t.stride(), t.shape
+            assert all(st[i] == st[i + 1] * sh[i + 1] for i in range(len(sh) - 2)), "add_n_rows: leading dims do not collapse"
+            lds.append(st[-2])
+        else:
+            lds.append(cols)
+        assert _avail(t) >= (rows - 1) * lds[-1] + cols
+    out = torch.empty(shape, dtype=_F32, device=tensors[0].device)
+    arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
+    ld = (ctypes.c_longlong * k)(*lds)
+    lib.call("cape_add_n_rows_f32", arr, ld, k, _p(out), rows, cols, _stream())
+    return out
+
+
 def gelu(x):
     _chk(x, "gelu.x")
     out = torch.empty_like(x)
@@ -922,9 +953,11 @@ def loss_fwd_bwd(logits, coords, labels, vis_u8, target, class_w, w_ce, w_l1, lo
     return losses, total, d_logits, d_coords
 
 
-def sumsq(g, out):
-    _chk(g, "sumsq.g"); _chk(out, "sumsq.out")
-    lib.call("cape_sumsq", _p(g), g.numel(), _p(out), _stream())
+def sumsq(g, out_parts):
+    """out_parts[b] = partial sum of squares of block b (lib.SUMSQ_PARTS floats; summed in a fixed order by adamw_step)."""
+    _chk(g, "sumsq.g"); _chk(out_parts, "sumsq.out", contiguous=False)
+    assert out_parts.numel() >= lib.SUMSQ_PARTS and out_parts.stride(-1) == 1
+    lib.call("cape_sumsq", _p(g), g.numel(), _p(out_parts), _stream())
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, max_norm, sumsq_t, step_t, lr_dev=None):
@@ -936,8 +969,9 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, max_norm, sumsq_t, step_t,
     if lr_dev is not None:
         _chk(lr_dev, "adamw.lr_dev", contiguous=False)
         assert lr_dev.numel() == 1
+    n_parts = sumsq_t.numel() if sumsq_t is not None else 0
     lib.call("cape_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-             float(wd), float(max_norm), _p(sumsq_t), _p(step_t), _p(lr_dev), _stream())
+             float(wd), float(max_norm), _p(sumsq_t), n_parts, _p(step_t), _p(lr_dev), _stream())
 
 
 def step_increment(step_t):

@@ -215,6 +215,34 @@ class EpisodeDataParallel:
             st["_events"] = (ev0, ev1)              # read lazily: elapsed_time needs both events complete
         self._reset_pending()
 
+    def allreduce_all(self):
+        """Every bucket, now: the exchange of a step whose backward was replayed from a hipGraph (runtime/graph_step.py) -- no hook
+        ran, the gradients of the whole pass are in the arenas when the replay has been enqueued.  Not overlapped with the
+        backward (one graph), but the host side of the step shrinks to two replays and `len(buckets)` collective calls."""
+        if self.world < 2:
+            return
+        ev0 = ev1 = None
+        if self.comm_stream is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
+        self._launched, self._order = set(), []
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        if self.comm_stream is not None:
+            ev1 = torch.cuda.Event(enable_timing=True); ev1.record(self.comm_stream)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self.steps_done += 1
+        st = self.stats
+        st["steps"] += 1
+        st["bytes_per_step"] = sum(4 * (hi - lo) for _, lo, hi, _ in self.buckets)
+        st["launch_order"] = list(self._order)
+        st["launched_before_finish"] = 0
+        if ev0 is not None:
+            st["_events"] = (ev0, ev1)
+        self._reset_pending()
+
     def exposed_comm_ms(self):
         """Time the last step's communication ran past the end of its backward (0 = fully overlapped).  Synchronises."""
         ev = self.stats.get("_events")

@@ -37,7 +37,10 @@ class ArenaAdamW(torch.optim.Optimizer):
         # keeps following the schedule -- `sync_lr` uploads param_groups[i]["lr"] when a scheduler changed it
         self.lr_dev = torch.tensor([lr, lr_backbone], dtype=torch.float32, device=device)
         self._lr_host = [lr, lr_backbone]
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        # per-block partial sums of squares of the two gradient arenas (no atomics: replicas compute identical clip coefficients)
+        from ..hip import lib as _lib
+        self._parts = _lib.SUMSQ_PARTS
+        self.sumsq = torch.zeros(2 * self._parts, dtype=torch.float32, device=device)
         # weight-gradient kernels may now accumulate straight into the gradient arenas (hip/functional.py)
         HF.Runtime.direct_grad = device.type == "cuda"
 
@@ -52,11 +55,10 @@ class ArenaAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         self.sync_lr()
         HF.Runtime.join()                       # side-stream wgrad kernels must have landed in the arenas
-        self.sumsq.zero_()
         if self.max_norm > 0:
-            for a in self.arenas:
+            for i, a in enumerate(self.arenas):
                 if a.numel:
-                    ops.sumsq(a.grad, self.sumsq)
+                    ops.sumsq(a.grad, self.sumsq[i * self._parts:(i + 1) * self._parts])
         ops.step_increment(self.step_count)
         for gi, (a, g) in enumerate(zip(self.arenas, self.param_groups)):
             if a.numel:
@@ -75,7 +77,7 @@ class ArenaAdamW(torch.optim.Optimizer):
 
     def grad_norm(self):
         """Global gradient norm of the last `step` (device tensor, no sync)."""
-        return self.sumsq.sqrt()
+        return self.sumsq.sum().sqrt()
 
     # ---- torch-format state dicts, ids as the reference's optimizer assigns them ------------------------------
     def state_dict(self):

@@ -355,6 +355,9 @@ int cape_level_embed_add(const float* base, const float* level_embed, const int*
 /* out = srcs[0] + ... + srcs[k-1] (k <= 8 host-array of device pointers, n elements each): the gradient fan-in of a tensor with
  * several consumers in one pass (what autograd's InputBuffer does with k-1 `at::add` launches). */
 int cape_add_n_f32(const float* const* srcs, int k, float* out, long long n, cape_stream_t stream);
+/* the same for (rows, cols) sources with row strides lds[j] (cols % 4 == 0): a summand may be a column block of a wider buffer */
+int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long rows, int cols,
+                        cape_stream_t stream);
 int cape_gelu_f32(const float* x, float* out, long long n, cape_stream_t stream);
 /* out[r][c] = x[r][c] + y[r][c] * gamma[c] (gamma may be NULL): residual behind LayerScale (models/bixattn.py:5-31,135-141) */
 int cape_scale_residual_f32(const float* x, const float* y, const float* gamma, float* out, long long rows, int C,
@@ -450,13 +453,16 @@ int cape_loss_fwd_bwd(const float* logits, const float* coords, const int64_t* l
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer over flat arenas (train_cape_episodic.py:527-538, engine_cape.py:240-258):
- *   cape_sumsq: out[0] (+)= sum g^2 ; cape_adamw_step: clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6))
- *   read from device, torch.optim.AdamW semantics (decoupled weight decay, bias correction with `step`
- *   read from device step_count[0], incremented by cape_step_increment).
+ *   cape_sumsq: out[b] = partial sum of g^2 of block b, b < CAPE_SUMSQ_PARTS (no atomics: the reduction order is fixed, so data-
+ *   parallel replicas that hold the same all-reduced gradient compute the same clip coefficient bit for bit);
+ *   cape_adamw_step: clip coefficient min(1, max_norm / (sqrt(sum of the n_parts partial sums) + 1e-6)) read from the device,
+ *   torch.optim.AdamW semantics (decoupled weight decay, bias correction with `step` read from device step_count[0],
+ *   incremented by cape_step_increment).
  * ---------------------------------------------------------------------------------------------- */
-int cape_sumsq(const float* g, long long n, float* out, cape_stream_t stream);
+#define CAPE_SUMSQ_PARTS 256
+int cape_sumsq(const float* g, long long n, float* out_parts, cape_stream_t stream);
 int cape_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, float max_norm, const float* sumsq,
+                    float beta2, float eps, float weight_decay, float max_norm, const float* sumsq_parts, int n_parts,
                     const int64_t* step_count, const float* lr_dev /* device scalar overriding `lr` when not NULL: a captured
                     step follows the learning-rate schedule (torch.optim.lr_scheduler writes param_groups[i]["lr"]) */,
                     cape_stream_t stream);

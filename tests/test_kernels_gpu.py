@@ -801,19 +801,24 @@ def test_adamw_matches_torch():
     opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=1e-2)
     pd, md, vd = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     step = torch.zeros(1, dtype=torch.int64, device=DEV)
-    ss = torch.zeros(1, device=DEV)
+    from cape_amd.hip import lib
+    ss = torch.full((lib.SUMSQ_PARTS,), 7.0, device=DEV)       # partial sums: every slot is rewritten by cape_sumsq
     for it in range(3):
         g = g0 * (it + 1)
         p.grad = g.clone()
         torch.nn.utils.clip_grad_norm_([p], 0.1)
         opt.step()
-        ss.zero_()
         gd = g.to(DEV)
         ops.sumsq(gd, ss)
         ops.step_increment(step)
         ops.adamw_step(pd, gd, md, vd, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.1, ss, step)
-    assert abs(math.sqrt(ss.item()) - (g0 * 3).norm().item()) < 1e-2
+    assert abs(math.sqrt(ss.sum().item()) - (g0 * 3).norm().item()) < 1e-2
     close(pd, p.detach(), tol=1e-6, name="adamw")
+    # no atomics anywhere in the norm: two evaluations agree bit for bit (data-parallel replicas must clip identically)
+    big = rnd(3_000_001, seed=9).to(DEV)
+    s1, s2 = torch.empty(lib.SUMSQ_PARTS, device=DEV), torch.empty(lib.SUMSQ_PARTS, device=DEV)
+    ops.sumsq(big, s1); ops.sumsq(big, s2)
+    assert torch.equal(s1, s2) and abs(s1.sum().item() / float((big.double() ** 2).sum()) - 1.0) < 1e-5
 
 
 def test_decode_next_tokens_matches_oracle():
@@ -880,7 +885,7 @@ def test_gemm_wgrad_fused_bias_sums(Mo, Ni, Kr, sk, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])
-@pytest.mark.parametrize("M", [6400, 130])
+@pytest.mark.parametrize("M", [6400, 130, 20])        # 20 rows: the skinny (M <= 64) kernel
 def test_gemm_column_limited_residual_and_batched_bias(prec, M):
     """Round 3 epilogue forms of the decoder's self-attention node: (a) one product over stacked weight rows with a residual of
     its own leading dimension on the first `res_cols` columns only (q | k | v = tgt [Wq; Wk; Wv]^T, `+ query_pos` on q);
@@ -1012,6 +1017,19 @@ def test_gemm_group_conv_wgrads():
     ops.gemm_group(descs, shapes, 64)
     for i, (dw, ref) in enumerate(refs):
         close(dw, ref, tol=2e-4, name=f"conv wgrad group item {i}")
+
+
+def test_add_n_rows_strided_sources():
+    """cape_add_n_rows_f32: a summand may be a column block of a wider buffer (the q part of the decoder's [dq | dk | dv] gradient)."""
+    wide = rnd(3, 50, 768, seed=1).to(DEV)
+    a, b, c = wide[..., :256], rnd(3, 50, 256, seed=2).to(DEV), wide[..., 512:]
+    close(ops.add_n_rows([a, b, c]), (a + b + c).cpu(), tol=1e-6, name="add_n_rows")
+    from cape_amd.hip import functional as HF
+    x = torch.randn(3, 50, 256, device=DEV, requires_grad=True)
+    u, v = HF.fanout(x, 2)
+    g = torch.randn(3, 50, 768, device=DEV)
+    torch.autograd.backward([u, v], [g[..., 256:512], g[..., :256].contiguous()])
+    close(x.grad, (g[..., 256:512] + g[..., :256]).cpu(), tol=1e-6, name="fan-in of a strided gradient")
 
 
 def test_gradient_slots_match_summation_pass(monkeypatch):

@@ -96,6 +96,32 @@ def worker(rank, world, port):
             print(f"rank {rank}:   {name}: err {d:.3e} (max |grad| {m:.3e})", flush=True)
     assert len(ddp.buckets) >= 4, len(ddp.buckets)
     assert ok, "gradient mismatch"
+    # ---- the captured step under data parallelism (runtime/graph_step.py with ddp=): two graphs around allreduce_all().  Every
+    # rank feeds ITS batch; after eager -> capture + replay -> replay the replicas must still hold identical parameters, and the
+    # replayed step must have moved them like an eager data-parallel step from the same state does
+    from cape_amd.runtime.graph_step import GraphedTrainStep
+    opt.zero_grad()
+    gstep = GraphedTrainStep(model, crit, opt, loss_scale=ddp.loss_scale, edge_capacity=256, eager_steps=1, ddp=ddp)
+    im, sc, sm, tg, sk = batches[rank]
+    snap = [a.data.clone() for a in opt.arenas]
+    steps_before = ddp.stats["steps"]
+    for i in range(3):
+        losses = gstep(im, sc, sm, tg, sk)
+        if os.environ.get("CAPE_REHEARSAL_STEP_SYNC"):
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for ai, a in enumerate(opt.arenas):
+        both = [torch.zeros_like(a.data) for _ in range(world)]
+        dist.all_gather(both, a.data)
+        d = (both[0] - both[1]).abs()
+        print(f"rank {rank}: after 3 graphed steps: arena {ai} max |param(rank0) - param(rank1)| = {float(d.max()):.3e} ({int((d > 0).sum())} of {d.numel()} differ)", flush=True)
+        assert float(d.max()) == 0.0, "replicas diverged under the graphed data-parallel step"
+    assert len(gstep.cache) == 1 and next(iter(gstep.cache.values())).graph2 is not None
+    assert ddp.stats["steps"] == steps_before + 3 and torch.isfinite(losses["_total"]).all()
+    moved = sum(float((a.data - s0).abs().sum()) for a, s0 in zip(opt.arenas, snap))
+    assert moved > 0
+    print(f"rank {rank}: graphed data-parallel step ok (3 steps, replicas identical, exposed comm of the last step "
+          f"{ddp.exposed_comm_ms():.3f} ms)", flush=True)
     dist.barrier()
     if rank == 0:
         print(f"ddp rehearsal ok: {len(ddp.buckets)} buckets", flush=True)

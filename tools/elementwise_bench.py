@@ -55,7 +55,7 @@ def main():
     us = t(lambda: ops.relu_drop_bwd(a, yb, 1.0))
     print(f"relu_drop_bwd      67 MB: {us:6.1f} us  ({3 * mb2 / us:5.2f} GB/ms for 3 passes)")
     # gradient norm over one 23 M-float arena
-    gflat = torch.randn(23_000_000, device=dev); acc = torch.zeros(1, device=dev)
+    gflat = torch.randn(23_000_000, device=dev); acc = torch.zeros(256, device=dev)
     us = t(lambda: ops.sumsq(gflat, acc))
     print(f"sumsq 92 MB             : {us:6.1f} us  ({92.0 / us:5.2f} GB/ms)")
     # GroupNorm of input_proj level 0: N = 32, HW = 1024, C = 256
