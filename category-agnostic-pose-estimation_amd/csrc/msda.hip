@@ -576,6 +576,145 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_kernel(const float* __res
   }
 }
 
+// Fixed-point form of the value kernel (the default of the bf16x3 product path; the exact-fp32 leg keeps the fp64 slab).
+// An LDS accumulator is one 64-bit INTEGER holding TWO channels: ds_add_u64 costs 6.3 clocks per wave-instruction against 8.0
+// for ds_add_f64 (tools/lab/lds_atomic_bench.hip) and covers two channels, so a block owns 16 channels of a head where the
+// fp64 slab holds 8 -- half the blocks, and the sampling geometry of every query is rebuilt twice per head instead of 4 times.
+//   * packing: a contribution pair (v0, v1), both int32, is added as the 64-bit value v1 * 2^32 + v0 (v0 sign-extended), so
+//     the slab word is exactly (sum v1) * 2^32 + (sum v0): no carry error, decoded at the end as lo = (int32)word,
+//     hi = (int32)(word >> 32) - (lo >> 31).
+//   * scale: v = rint(go * w * 2^s) with s chosen per block from gmax = max |d_out| over the block's 16 channels and all
+//     queries: the softmax weights of a (query, head) sum to 1 and the bilinear weights of a sample to <= 1, so one pixel
+//     receives at most |go_q| per query and |sum| <= Lq * gmax; with 2^s = 2^30 / (pow2ceil(Lq) * pow2ceil(gmax)) a sum can
+//     never leave int32 (rounding adds at most half a unit per contribution, < 2^17 units).  The quantum is
+//     pow2ceil(Lq) * pow2ceil(gmax) * 2^-30 (Lq = 1360: <= 4e-6 gmax relative to the block's largest incoming gradient).
+//   * a non-finite d_out (inf / NaN) has no fixed-point image: the block then writes NaN to its whole d_value slice.
+template <int VP>
+__global__ void __launch_bounds__(1024) msda_bwd_value_fx_kernel(const float* __restrict__ d_out, const float* __restrict__ offw,
+                                                                 const float* __restrict__ ref, float* __restrict__ d_value,
+                                                                 Levels lv, int N, int S, int Lq, int L, int P) {
+  constexpr int VC = 2 * VP, GROUPS = HD / VC, BPI = HEADS * GROUPS;   // channels per block, channel groups per head, blocks per image
+  constexpr int SLOTS = 64 / VP;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long fslab[];   // [(S + 1)][VP]; row S swallows taps outside a level
+  __shared__ uint2 rec_ids[16][64];
+  __shared__ float4 rec_w[16][64];
+  __shared__ unsigned gmax_w[16];
+  int n, sub;
+  {
+    const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;
+    n = (loc / BPI) * 8 + xcd;
+    sub = loc % BPI;
+    if (n >= N) return;
+  }
+  const int h = sub / GROUPS, grp = sub % GROUPS;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ch0 = h * HD + grp * VC;
+  for (int k = threadIdx.x; k < (S + 1) * VP; k += 1024) fslab[k] = 0ull;
+  // block maximum of |d_out| over (all queries, the block's channels), as ordered bit patterns (NaN > inf > finite)
+  unsigned gb = 0u;
+  for (int k = threadIdx.x; k < Lq * VP; k += 1024) {
+    const int q = k / VP, c2 = (k - q * VP) * 2;
+    const float2 v = *reinterpret_cast<const float2*>(d_out + ((long long)n * Lq + q) * CH + ch0 + c2);
+    gb = max(gb, max(__float_as_uint(fabsf(v.x)), __float_as_uint(fabsf(v.y))));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) gb = max(gb, (unsigned)__shfl_xor((int)gb, o));
+  if (lane == 0) gmax_w[wv] = gb;
+  __syncthreads();
+  gb = gmax_w[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) gb = max(gb, gmax_w[k]);
+  const bool finite = gb < 0x7f800000u;
+  float scale = 0.f, inv_scale = 0.f;
+  if (finite && gb != 0u) {
+    int e;
+    (void)frexpf(__uint_as_float(gb), &e);                       // gmax <= 2^e
+    const int lq_bits = Lq > 1 ? 32 - __clz(Lq - 1) : 0;         // pow2ceil(Lq) = 2^lq_bits
+    const int sx = max(-126, min(126, 30 - lq_bits - e));
+    scale = ldexpf(1.f, sx);
+    inv_scale = ldexpf(1.f, -sx);
+  }
+
+  const int g = lane >> 4, j = lane & 15;                        // phase 1: (query, sample)
+  const int c = lane & (VP - 1), slot = lane / VP;               // phase 2: channel pair c; records slot*VP .. slot*VP+VP-1
+  static_assert(SLOTS * VP == 64 && 16 % VP == 0, "a slot's records must stay inside one query");
+  const int LP = L * P;
+  const int rowlen = HEADS * LP * 3;
+  const int choff = ch0 + 2 * c;
+  const int l_own = j < LP ? j / P : 0;
+  const int W = sel4(lv.W, l_own), H = sel4(lv.H, l_own), st = sel4(lv.start, l_own);
+  const float Wf = (float)W, Hf = (float)H;
+  const int g2 = (slot * VP) >> 4;
+  struct In { float2 rr, oo, go; float lg; };
+  auto fetch = [&](int qb) {
+    In in;
+    const int q = qb + g, q2 = qb + g2;
+    const long long qrow = (long long)n * Lq + min(q, Lq - 1);
+    const float* ow = offw + qrow * rowlen;
+    const int jj = min(j, LP - 1);
+    in.rr = *reinterpret_cast<const float2*>(ref + (qrow * L + l_own) * 2);
+    in.oo = *reinterpret_cast<const float2*>(ow + (h * LP + jj) * 2);
+    in.lg = ow[HEADS * LP * 2 + h * LP + jj];
+    in.go = *reinterpret_cast<const float2*>(d_out + ((long long)n * Lq + min(q2, Lq - 1)) * CH + choff);
+    return in;
+  };
+  auto add2 = [&](unsigned pix, float wgt, float g0, float g1) {
+    const int v0 = __float2int_rn(g0 * wgt), v1 = __float2int_rn(g1 * wgt);
+    const unsigned long long pk = ((unsigned long long)(unsigned)(v1 + (v0 >> 31)) << 32) | (unsigned)v0;
+    atomicAdd(&fslab[pix * VP + c], pk);
+  };
+  In cur = fetch(wv * 4);
+  for (int qb = wv * 4; qb < Lq; qb += 64) {
+    const In nxt = fetch(min(qb + 64, Lq - 1));
+    const int q = qb + g;
+    const bool qlive = q < Lq;
+    {
+      const bool slive = qlive && j < LP;
+      const float px = (cur.rr.x + cur.oo.x / Wf) * Wf - 0.5f;
+      const float py = (cur.rr.y + cur.oo.y / Hf) * Hf - 0.5f;
+      const float lg = slive ? cur.lg : -INFINITY;
+      const float mx = max16(lg);
+      const float e = slive ? __expf(lg - mx) : 0.f;
+      const float sm = sum16(e);
+      const float aw = slive ? e / sm : 0.f;
+      const Tap t = make_tap(px, py, W, H, st, slive, S);
+      rec_ids[wv][lane] = make_uint2(t.i00 | (t.i01 << 16), t.i10 | (t.i11 << 16));
+      rec_w[wv][lane] = make_float4(aw * (1.f - t.fx) * (1.f - t.fy), aw * t.fx * (1.f - t.fy), aw * (1.f - t.fx) * t.fy,
+                                    aw * t.fx * t.fy);
+    }
+    const bool live2 = qb + g2 < Lq;
+    const float g0 = live2 ? cur.go.x * scale : 0.f, g1 = live2 ? cur.go.y * scale : 0.f;
+    const int rbase = slot * VP;
+#pragma unroll
+    for (int s = 0; s < VP; ++s) {
+      const uint2 ids = rec_ids[wv][rbase + s];
+      const float4 w = rec_w[wv][rbase + s];
+      add2(ids.x & 0xFFFFu, w.x, g0, g1);
+      add2(ids.x >> 16, w.y, g0, g1);
+      add2(ids.y & 0xFFFFu, w.z, g0, g1);
+      add2(ids.y >> 16, w.w, g0, g1);
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  float* dvb = d_value + (long long)n * S * CH + ch0;
+  const float nanv = __uint_as_float(0x7fc00000u);
+  auto dec = [&](unsigned long long wd, float& lo, float& hi) {
+    const int l = (int)(unsigned)wd;
+    const int hh = (int)(unsigned)(wd >> 32) - (l >> 31);
+    lo = finite ? (float)l * inv_scale : nanv;
+    hi = finite ? (float)hh * inv_scale : nanv;
+  };
+  constexpr int Q = VP / 2;                                      // float4 stores per pixel row
+  for (int k = threadIdx.x; k < S * Q; k += 1024) {
+    const int p_ = k / Q, c2 = (k % Q) * 2;
+    float4 o;
+    dec(fslab[p_ * VP + c2], o.x, o.y);
+    dec(fslab[p_ * VP + c2 + 1], o.z, o.w);
+    *reinterpret_cast<float4*>(dvb + (long long)p_ * CH + c2 * 2) = o;
+  }
+}
+
 int fill_levels(Levels& lv, const int* shapes, const int* level_start, int L, int S) {
   CAPE_REQUIRE(L >= 1 && L <= 4, "cape_msda: L=%d must be in 1..4", L);
   long long tot = 0;
@@ -646,6 +785,13 @@ extern "C" int cape_msda_bwd_atomic(const float* d_out, const float* value, cons
 extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
                              const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
                              int N, int S, int Lq, int L, int P, cape_stream_t stream) {
+  return cape_msda_bwd_ex(d_out, value, offw, ref, shapes, level_start, d_value, d_offw, d_ref, N, S, Lq, L, P, 0, stream);
+}
+
+extern "C" int cape_msda_bwd_ex(const float* d_out, const float* value, const float* offw, const float* ref,
+                                const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
+                                int N, int S, int Lq, int L, int P, int value_accum, cape_stream_t stream) {
+  CAPE_REQUIRE(value_accum == 0 || value_accum == 1, "cape_msda_bwd_ex: value_accum must be 0 (fp64 slab) or 1 (fixed-point pairs)");
   if (msda_bwd_check(d_out, value, offw, ref, shapes, level_start, d_value, d_offw, L, P)) return 1;
   if (N <= 0 || Lq <= 0) return 0;
   // split form when the (image, head, 8-channel) fp64 slab fits in LDS (S <= ~2300: every image size up to 320x320);
@@ -670,6 +816,12 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_kernel<2>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_fx_kernel<8>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_fx_kernel<4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_fx_kernel<2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSlab);
     if (e != hipSuccess) return cape_set_error("cape_msda_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
@@ -680,7 +832,19 @@ extern "C" int cape_msda_bwd(const float* d_out, const float* value, const float
 #define VALUE_LAUNCH(W)                                                                                                     \
   hipLaunchKernelGGL((msda_bwd_value_kernel<W>), dim3((unsigned)vblocks), dim3(1024), slab_bytes, as_stream(stream), d_out, offw, \
                      ref, d_value, lv, N, S, Lq, L, P)
-  if (vc == 8) VALUE_LAUNCH(8); else if (vc == 4) VALUE_LAUNCH(4); else VALUE_LAUNCH(2);
+#define VALUE_LAUNCH_FX(W)                                                                                                  \
+  hipLaunchKernelGGL((msda_bwd_value_fx_kernel<W>), dim3((unsigned)fxblocks), dim3(1024), fx_bytes, as_stream(stream),           \
+                     d_out, offw, ref, d_value, lv, N, S, Lq, L, P)
+  if (value_accum == 1) {                                        // same slab bytes (8 per accumulator), twice the channels per block
+    int vp = vc;                                                 // few images: narrower blocks until every CU has one
+    while (vp > 2 && imgs8 * 8 * HEADS * (HD / (2 * vp)) < 256) vp >>= 1;
+    const long long fxblocks = imgs8 * 8 * HEADS * (HD / (2 * vp));
+    const size_t fx_bytes = (size_t)(S + 1) * vp * sizeof(unsigned long long);
+    if (vp == 8) VALUE_LAUNCH_FX(8); else if (vp == 4) VALUE_LAUNCH_FX(4); else VALUE_LAUNCH_FX(2);
+  } else {
+    if (vc == 8) VALUE_LAUNCH(8); else if (vc == 4) VALUE_LAUNCH(4); else VALUE_LAUNCH(2);
+  }
+#undef VALUE_LAUNCH_FX
 #undef VALUE_LAUNCH
   hipLaunchKernelGGL(msda_bwd_offw_kernel, dim3((unsigned)(imgs8 * 8 * bpi)), dim3(256), 0, as_stream(stream), d_out, value, offw,
                      ref, d_offw, d_ref, lv, N, S, Lq, L, P, bpi);

@@ -132,6 +132,7 @@ _SIGS = {
     "cape_groupnorm_bwd": [P, LL, P, P, P, P, P, P, P, I, I, I, I, P, c_size_t, P],
     "cape_msda_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_msda_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "cape_msda_bwd_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cape_msda_bwd_atomic": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "cape_attn_fwd": [P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],
     "cape_attn_bwd": [P, P, P, P, P, P, P, P, P, LL, LL, LL, LL, LL, LL, LL, LL, I, I, I, I, F, I, I, P, F, P, U32, P],

@@ -498,15 +498,24 @@ def msda_fwd(value, offw, ref, geo, N, Lq, P=4):
     return out
 
 
+MSDA_VALUE_ACCUM = os.environ.get("CAPE_MSDA_VALUE_ACCUM", "auto")          # auto | f64 | fx
+
+
 def msda_bwd(d_out, value, offw, ref, geo, N, Lq, P=4, need_ref_grad=True, form="split"):
     _chk(d_out, "msda_bwd.d_out")
     d_value = torch.empty_like(value)
     d_offw = torch.empty_like(offw)
     d_ref = torch.empty_like(ref) if need_ref_grad else None
-    # "split": LDS-slab scatter + gather kernel (falls back to atomics inside the library when the slab does not fit)
-    fn = {"split": "cape_msda_bwd", "atomic": "cape_msda_bwd_atomic"}[form]
-    lib.call(fn, _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
-             _p(d_offw), _p(d_ref), N, geo.S, Lq, geo.L, P, _stream())
+    # "split": LDS-slab scatter + gather kernel (falls back to atomics inside the library when the slab does not fit); its d_value
+    # accumulators are fixed-point pairs ("fx") except on the exact-fp32 leg, which keeps the fp64 slab ("f64")
+    if form == "split":
+        form = MSDA_VALUE_ACCUM if MSDA_VALUE_ACCUM != "auto" else ("f64" if GEMM_PRECISION == 0 else "fx")
+    if form == "atomic":
+        lib.call("cape_msda_bwd_atomic", _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
+                 _p(d_offw), _p(d_ref), N, geo.S, Lq, geo.L, P, _stream())
+    else:
+        lib.call("cape_msda_bwd_ex", _p(d_out), _p(value), _p(offw), _p(ref), geo._shapes_c, geo._starts_c, _p(d_value),
+                 _p(d_offw), _p(d_ref), N, geo.S, Lq, geo.L, P, {"f64": 0, "fx": 1}[form], _stream())
     return d_value, d_offw, d_ref
 
 

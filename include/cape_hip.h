@@ -284,6 +284,14 @@ int cape_msda_fwd(const float* value, const float* offw, const float* ref, const
 int cape_msda_bwd(const float* d_out, const float* value, const float* offw, const float* ref,
                   const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
                   int N, int S, int Lq, int L, int P, cape_stream_t stream);
+/* the same backward with the accumulator type of the d_value slab chosen by the caller: value_accum 0 = fp64 LDS accumulators
+ * (8 channels per block; what cape_msda_bwd does: the sum is rounded to fp32 once), 1 = 64-bit integer accumulators holding two
+ * channels each as block-scaled 32-bit fixed point (16 channels per block, ~2x faster; quantum <= pow2ceil(Lq) * 2^-29 of the
+ * block's largest |d_out|, cannot overflow; a non-finite d_out makes the block's d_value slice NaN).  The product path uses 1
+ * with the bf16x3 / bf16 GEMM modes and 0 on the exact-fp32 leg. */
+int cape_msda_bwd_ex(const float* d_out, const float* value, const float* offw, const float* ref,
+                     const int* shapes, const int* level_start, float* d_value, float* d_offw, float* d_ref,
+                     int N, int S, int Lq, int L, int P, int value_accum, cape_stream_t stream);
 /* any-geometry form of the same backward: memory-side float atomics into d_value (what cape_msda_bwd falls back to when
  * the (S+1) x 8 fp64 gradient slab of one (image, head, channel group) does not fit in LDS). */
 int cape_msda_bwd_atomic(const float* d_out, const float* value, const float* offw, const float* ref,

@@ -382,7 +382,7 @@ def _msda_ref(value, offw, ref, shapes):
                                          (3, 70, [(32, 32), (16, 16), (8, 8), (4, 4)]),
                                          (2, 90, [(48, 48), (24, 24), (12, 12), (6, 6)]),      # S = 3060: 4-channel slabs
                                          (1, 130, [(64, 64), (32, 32), (16, 16), (8, 8)])])    # S = 5440: 2-channel slabs
-@pytest.mark.parametrize("form", ["split", "atomic"])
+@pytest.mark.parametrize("form", ["f64", "fx", "atomic"])          # d_value accumulators: fp64 LDS slab | fixed-point pairs | memory atomics
 def test_msda_fwd_bwd(N, Lq, shapes, form):
     value, offw, ref = _msda_inputs(N, Lq, shapes, 11)
     value.requires_grad_(True); offw.requires_grad_(True); ref.requires_grad_(True)
@@ -401,6 +401,57 @@ def test_msda_fwd_bwd(N, Lq, shapes, form):
     assert dr2 is None
     close(dv2, value.grad, tol=3e-4, name="msda d_value (no d_ref)")
     close(do2, offw.grad, tol=3e-4, name="msda d_offw (no d_ref)")
+
+
+def test_msda_value_gradient_fixed_point_bounds():
+    """The fixed-point d_value slab (csrc/msda.hip msda_bwd_value_fx_kernel) against the fp64 slab on the cases its scale is
+    chosen for: (a) every query of an image puts all its weight on ONE pixel (the largest sum the softmax allows: Lq * gmax --
+    must not overflow); (b) channels 1e6 apart in one block (the small channel is quantised against the block's largest
+    gradient: absolute, not relative, accuracy); (c) an all-zero and a denormal-small d_out; (d) a NaN in d_out poisons the
+    (image, channel block) slice it belongs to instead of vanishing in the integer conversion."""
+    shapes = [(32, 32), (16, 16), (8, 8), (4, 4)]
+    geo = ops.LevelGeometry(shapes)
+    N, Lq = 2, 1360
+    value, offw, ref = _msda_inputs(N, Lq, shapes, 21)
+    vd = value.to(DEV)
+
+    def both(go, offw_, ref_):
+        a = ops.msda_bwd(go.to(DEV), vd, offw_.to(DEV), ref_.to(DEV), geo, N, Lq, form="f64")[0]
+        b = ops.msda_bwd(go.to(DEV), vd, offw_.to(DEV), ref_.to(DEV), geo, N, Lq, form="fx")[0]
+        return a.cpu(), b.cpu()
+
+    def quantum(gmax):                                           # pow2ceil(Lq) * pow2ceil(gmax) * 2^-30
+        return 2.0 ** (11 + int(np.ceil(np.log2(gmax))) - 30)
+
+    # (a) collision: zero offsets, one reference point at a pixel centre of level 0, logits select sample 0 only
+    offw_c = torch.zeros(N, Lq, 384)
+    offw_c[..., 256:] = -1e4
+    offw_c[..., 256::16] = 0.0                                   # sample 0 of every head
+    ref_c = torch.full((N, Lq, 4, 2), (5 + 0.5) / 32)
+    go = torch.ones(N, Lq, 256) * 3.0
+    a, b = both(go, offw_c, ref_c)
+    assert abs(float(a.abs().max()) - 3.0 * Lq) < 1e-2           # the whole image's gradient on one pixel
+    assert (a - b).abs().max() <= Lq * 0.5 * quantum(3.0) + 1e-3
+    # (b) dynamic range inside a block + generic taps
+    go = rnd(N, Lq, 256, seed=6)
+    go[..., 1::16] *= 1e-6
+    a, b = both(go, offw, ref)
+    gmax = float(go.abs().max())
+    assert (a - b).abs().max() <= 64 * quantum(gmax), ((a - b).abs().max(), quantum(gmax))
+    small = (a.view(N, -1, 256)[..., 1::16] - b.view(N, -1, 256)[..., 1::16]).abs().max()
+    assert small <= 64 * quantum(gmax)                           # absolute bound only: the small channel's own scale is 1e-6 gmax
+    # (c) zero and tiny gradients
+    a, b = both(torch.zeros(N, Lq, 256), offw, ref)
+    assert float(b.abs().max()) == 0.0 and float(a.abs().max()) == 0.0
+    a, b = both(rnd(N, Lq, 256, seed=7) * 1e-30, offw, ref)
+    assert torch.isfinite(b).all() and (a - b).abs().max() <= 64 * quantum(4e-30)
+    # (d) NaN
+    go = rnd(N, Lq, 256, seed=8)
+    go[1, 77, 40] = float("nan")                                 # image 1, head 1; the block is 4..16 channels wide (by image count)
+    a, b = both(go, offw, ref)
+    bv = b.view(N, -1, 256)
+    assert torch.isnan(bv[1, :, 40:44]).all() and torch.isfinite(bv[0]).all()
+    assert torch.isfinite(bv[1, :, :32]).all() and torch.isfinite(bv[1, :, 48:]).all()
 
 
 def test_msda_core_against_reference_golden(golden_dir):

@@ -32,7 +32,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print(f"N={N} Lq={Lq} forward: {e0.elapsed_time(e1) / 20 * 1e3:9.1f} us", flush=True)
-        for form in ("atomic", "split"):
+        for form in ("atomic", "f64", "fx"):
             for need_ref in (False,):
                 for _ in range(3):
                     ops.msda_bwd(go, value, offw, ref, geo, N, Lq, need_ref_grad=need_ref, form=form)
