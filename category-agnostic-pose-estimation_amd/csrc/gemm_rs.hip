@@ -30,8 +30,10 @@ constexpr int RS_UNIT = 64;                       // rows per unit
 #ifdef RS_STAMPS                                  // lab builds only (tools/lab/rs_lab.hip): per-block phase time stamps
 __device__ long long* g_rs_stamps;
 #define RS_STAMP(i) do { if (threadIdx.x == 0 && (i) < 16) g_rs_stamps[blockIdx.x * 16 + (i)] = clock64(); } while (0)
+#define RS_FINE(cond, i) do { if ((cond) && threadIdx.x == 0) g_rs_stamps[blockIdx.x * 16 + 8 + (i)] = clock64(); } while (0)
 #else
 #define RS_STAMP(i) do {} while (0)
+#define RS_FINE(cond, i) do {} while (0)
 #endif
 
 template <int KS>
@@ -220,6 +222,7 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      RS_FINE(u == slot + gpc, 3 * hh);
       const int ao = (32 * half + r) * LD + 8 * h;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -232,6 +235,7 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[s], acc, 0, 0, 0);
         if (hh == H1 - 1 && s >= KS - NV && has_next) store_piece(ra[s - (KS - NV)], s - (KS - NV), buf ^ 1);
       }
+      RS_FINE(u == slot + gpc, 3 * hh + 1);
       // C/D map of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).  The row base of
       // register i is wave-uniform (scalar address arithmetic); the lane part is a 32-bit offset.
       if (!col_ok) continue;
@@ -271,8 +275,10 @@ __global__ void __launch_bounds__(512) gemm_rs_kernel(const GemmP p, int nchunks
         }
       }
     }
+    RS_FINE(u == slot + gpc, 6);
     if (u + 2 * gpc < nunits) load_rows(ra, p.A, p.lda, (u + 2 * gpc) * RS_UNIT, p.M);
     __syncthreads();
+    RS_FINE(u == slot + gpc, 7);
     RS_STAMP(stamp_i); ++stamp_i;
     buf ^= 1;
   }

@@ -583,12 +583,14 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_kernel(const float* __res
 //   * packing: a contribution pair (v0, v1), both int32, is added as the 64-bit value v1 * 2^32 + v0 (v0 sign-extended), so
 //     the slab word is exactly (sum v1) * 2^32 + (sum v0): no carry error, decoded at the end as lo = (int32)word,
 //     hi = (int32)(word >> 32) - (lo >> 31).
-//   * scale: v = rint(go * w * 2^s) with s chosen per block from gmax = max |d_out| over the block's 16 channels and all
+//   * scale: v = rint(go * w * 2^s) (one contribution <= 2^21) with s chosen per block from gmax = max |d_out| over the block's 16 channels and all
 //     queries: the softmax weights of a (query, head) sum to 1 and the bilinear weights of a sample to <= 1, so one pixel
 //     receives at most |go_q| per query and |sum| <= Lq * gmax; with 2^s = 2^30 / (pow2ceil(Lq) * pow2ceil(gmax)) a sum can
 //     never leave int32 (rounding adds at most half a unit per contribution, < 2^17 units).  The quantum is
 //     pow2ceil(Lq) * pow2ceil(gmax) * 2^-30 (Lq = 1360: <= 4e-6 gmax relative to the block's largest incoming gradient).
 //   * a non-finite d_out (inf / NaN) has no fixed-point image: the block then writes NaN to its whole d_value slice.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int VP>
 __global__ void __launch_bounds__(1024) msda_bwd_value_fx_kernel(const float* __restrict__ d_out, const float* __restrict__ offw,
                                                                  const float* __restrict__ ref, float* __restrict__ d_value,
@@ -596,7 +598,7 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_fx_kernel(const float* __
   constexpr int VC = 2 * VP, GROUPS = HD / VC, BPI = HEADS * GROUPS;   // channels per block, channel groups per head, blocks per image
   constexpr int SLOTS = 64 / VP;
   extern __shared__ __attribute__((aligned(16))) unsigned long long fslab[];   // [(S + 1)][VP]; row S swallows taps outside a level
-  __shared__ uint2 rec_ids[16][64];
+  __shared__ uint4 rec_off[16][64];                              // per wave: [query g (4)][sample j (16)] -> slab byte offsets of the corners
   __shared__ float4 rec_w[16][64];
   __shared__ unsigned gmax_w[16];
   int n, sub;
@@ -630,7 +632,8 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_fx_kernel(const float* __
     int e;
     (void)frexpf(__uint_as_float(gb), &e);                       // gmax <= 2^e
     const int lq_bits = Lq > 1 ? 32 - __clz(Lq - 1) : 0;         // pow2ceil(Lq) = 2^lq_bits
-    const int sx = max(-126, min(126, 30 - lq_bits - e));
+    // one contribution stays below 2^21 (the float -> int conversion below is exact up to 2^22), a sum below 2^30
+    const int sx = max(-126, min(126, min(30 - lq_bits, 21) - e));
     scale = ldexpf(1.f, sx);
     inv_scale = ldexpf(1.f, -sx);
   }
@@ -658,10 +661,15 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_fx_kernel(const float* __
     in.go = *reinterpret_cast<const float2*>(d_out + ((long long)n * Lq + min(q2, Lq - 1)) * CH + choff);
     return in;
   };
-  auto add2 = [&](unsigned pix, float wgt, float g0, float g1) {
-    const int v0 = __float2int_rn(g0 * wgt), v1 = __float2int_rn(g1 * wgt);
+  // rint(g * w) for both channels of the pair without a convert: one packed FMA onto 1.5 * 2^23 leaves the rounded integer
+  // (round-to-nearest-even of the exact product, |.| <= 2^22) in the low mantissa bits; the pair then goes out as
+  // hi * 2^32 + lo with lo sign-extended (see the kernel header)
+  char* const slab_c = reinterpret_cast<char*>(fslab) + c * 8;
+  auto add2 = [&](unsigned off, float wgt, v2f gg) {
+    const v2f t = __builtin_elementwise_fma(gg, (v2f)(wgt), (v2f)(12582912.f));
+    const int v0 = (int)__float_as_uint(t.x) - 0x4B400000, v1 = (int)__float_as_uint(t.y) - 0x4B400000;
     const unsigned long long pk = ((unsigned long long)(unsigned)(v1 + (v0 >> 31)) << 32) | (unsigned)v0;
-    atomicAdd(&fslab[pix * VP + c], pk);
+    atomicAdd(reinterpret_cast<unsigned long long*>(slab_c + off), pk);
   };
   In cur = fetch(wv * 4);
   for (int qb = wv * 4; qb < Lq; qb += 64) {
@@ -678,21 +686,23 @@ __global__ void __launch_bounds__(1024) msda_bwd_value_fx_kernel(const float* __
       const float sm = sum16(e);
       const float aw = slive ? e / sm : 0.f;
       const Tap t = make_tap(px, py, W, H, st, slive, S);
-      rec_ids[wv][lane] = make_uint2(t.i00 | (t.i01 << 16), t.i10 | (t.i11 << 16));
+      rec_off[wv][lane] = make_uint4(t.i00 * (VP * 8), t.i01 * (VP * 8), t.i10 * (VP * 8), t.i11 * (VP * 8));
       rec_w[wv][lane] = make_float4(aw * (1.f - t.fx) * (1.f - t.fy), aw * t.fx * (1.f - t.fy), aw * (1.f - t.fx) * t.fy,
                                     aw * t.fx * t.fy);
     }
     const bool live2 = qb + g2 < Lq;
-    const float g0 = live2 ? cur.go.x * scale : 0.f, g1 = live2 ? cur.go.y * scale : 0.f;
+    v2f gg;
+    gg.x = live2 ? cur.go.x * scale : 0.f;
+    gg.y = live2 ? cur.go.y * scale : 0.f;
     const int rbase = slot * VP;
 #pragma unroll
     for (int s = 0; s < VP; ++s) {
-      const uint2 ids = rec_ids[wv][rbase + s];
+      const uint4 off = rec_off[wv][rbase + s];
       const float4 w = rec_w[wv][rbase + s];
-      add2(ids.x & 0xFFFFu, w.x, g0, g1);
-      add2(ids.x >> 16, w.y, g0, g1);
-      add2(ids.y & 0xFFFFu, w.z, g0, g1);
-      add2(ids.y >> 16, w.w, g0, g1);
+      add2(off.x, w.x, gg);
+      add2(off.y, w.y, gg);
+      add2(off.z, w.z, gg);
+      add2(off.w, w.w, gg);
     }
     cur = nxt;
   }
@@ -796,7 +806,7 @@ extern "C" int cape_msda_bwd_ex(const float* d_out, const float* value, const fl
   if (N <= 0 || Lq <= 0) return 0;
   // split form when the (image, head, 8-channel) fp64 slab fits in LDS (S <= ~2300: every image size up to 320x320);
   // larger geometries take the memory-side-atomic form
-  const size_t kMaxSlab = 160 * 1024 - 16 * 64 * (sizeof(uint2) + sizeof(float4)) - 512;
+  const size_t kMaxSlab = 160 * 1024 - 16 * 64 * (sizeof(uint4) + sizeof(float4)) - 512;
   int vc = 8;                                                    // widest channel group whose slab fits
   while (vc >= 2 && (size_t)(S + 1) * vc * sizeof(double) > kMaxSlab) vc >>= 1;
   const size_t slab_bytes = (size_t)(S + 1) * vc * sizeof(double);

@@ -75,6 +75,11 @@ int main(int argc, char** argv) {
   double d[8] = {0}; int cnt[8] = {0};
   for (int b = 0; b < nb; ++b) for (int i = 1; i < 8 && h[b * 16 + i]; ++i) { d[i] += h[b * 16 + i] - h[b * 16 + i - 1]; cnt[i]++; }
   printf("  mean phase cycles:"); for (int i = 1; i < 8 && cnt[i]; ++i) printf(" %.0f", d[i] / cnt[i]); printf("\n");
+  // second unit of a block, wave 0: start of half 0 MFMAs | its MFMAs issued | (unused) | half 1 start | issued | (unused) | stores issued | barrier passed
+  double f[8] = {0}; int fc = 0;
+  for (int b = 0; b < nb; ++b) if (h[b * 16 + 8] && h[b * 16 + 15]) { for (int i = 0; i < 8; ++i) f[i] += (double)(h[b * 16 + 8 + i] - h[b * 16 + 8]); ++fc; }
+  if (fc) { printf("  second unit, wave 0, cycles from its first MFMA: h0 issued %.0f | h1 start %.0f | h1 issued %.0f | stores issued %.0f | barrier %.0f  (%d blocks)\n",
+                   f[1] / fc, f[3] / fc, f[4] / fc, f[6] / fc, f[7] / fc, fc); }
 #endif
   return 0;
 }
