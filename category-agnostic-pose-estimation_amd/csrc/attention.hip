@@ -189,14 +189,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
                                                            const float* __restrict__ O, const float* __restrict__ lse,
                                                            float* __restrict__ dQ, const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // keys / values are staged in panels of <= MAXL rows (one panel for every sequence of the CAPE step; the bidirectional
+  // blocks' 280-patch panels take two): the row's logsumexp is known, so the panels simply accumulate
+  const int KC = min(p.Lk, MAXL);
   float* Ks = smem;
-  float* Vs = smem + p.Lk * HD;
+  float* Vs = smem + KC * HD;
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
   const int i = blockIdx.x * ROWS + (threadIdx.x >> 2);
-  stage_rows(Ks, K + (long long)n * p.bsk + h * HD, p.ldk, p.Lk);
-  stage_rows(Vs, V + (long long)n * p.bsv + h * HD, p.ldv, p.Lk);
-  __syncthreads();
   const bool live = i < p.Lq;
   float q[8], go[8], acc[8];
   float D = 0.f, L = 0.f;
@@ -220,11 +220,19 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
   }
   const uint8_t* kp = p.mask_mode == 2 ? p.kpm + (long long)n * p.Lk : nullptr;
   const uint64_t rbase = (((uint64_t)n * p.H + h) * p.Lq + (uint64_t)(live ? i : 0)) * p.Lk;
-  for (int j = 0; j < jend; ++j) {
-    const float4 k0 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8);
-    const float4 k1 = *reinterpret_cast<const float4*>(Ks + j * HD + sub * 8 + 4);
-    const float4 v0 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(Vs + j * HD + sub * 8 + 4);
+  for (int kb = 0; kb < p.Lk; kb += MAXL) {
+  const int kc = min(MAXL, p.Lk - kb);
+  if (kb) __syncthreads();                     // everyone is done with the previous panel
+  stage_rows(Ks, K + (long long)n * p.bsk + (long long)kb * p.ldk + h * HD, p.ldk, kc);
+  stage_rows(Vs, V + (long long)n * p.bsv + (long long)kb * p.ldv + h * HD, p.ldv, kc);
+  __syncthreads();
+  const int jhi = min(kb + kc, jend);          // wave-uniform
+  for (int j = kb; j < jhi; ++j) {
+    const int jj = j - kb;
+    const float4 k0 = *reinterpret_cast<const float4*>(Ks + jj * HD + sub * 8);
+    const float4 k1 = *reinterpret_cast<const float4*>(Ks + jj * HD + sub * 8 + 4);
+    const float4 v0 = *reinterpret_cast<const float4*>(Vs + jj * HD + sub * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Vs + jj * HD + sub * 8 + 4);
     const float s = quad_sum(dot8(q, k0, k1));
     float dp = quad_sum(dot8(go, v0, v1));
     bool masked = !live;
@@ -236,6 +244,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     const float ds = pe * (dp - D) * p.scale;
     acc[0] += ds * k0.x; acc[1] += ds * k0.y; acc[2] += ds * k0.z; acc[3] += ds * k0.w;
     acc[4] += ds * k1.x; acc[5] += ds * k1.y; acc[6] += ds * k1.z; acc[7] += ds * k1.w;
+  }
   }
   if (live) {
     float* dp_ = dQ + (long long)n * p.bsq + (long long)i * p.ldq + h * HD + sub * 8;
@@ -250,10 +259,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
                                                             const float* __restrict__ O, const float* __restrict__ lse,
                                                             float* __restrict__ dK, float* __restrict__ dV, const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                       // [Lq][32]
-  float* Gs = smem + p.Lq * HD;           // dO [Lq][32]
-  float* Ds = smem + 2 * p.Lq * HD;       // D_i
-  float* Ls = Ds + p.Lq;                  // lse_i
+  const int QC = min(p.Lq, MAXL);        // queries are staged in panels of <= MAXL rows
+  float* Qs = smem;                       // [QC][32]
+  float* Gs = smem + QC * HD;             // dO [QC][32]
+  float* Ds = smem + 2 * QC * HD;         // D_i
+  float* Ls = Ds + QC;                    // lse_i
   const int n = blockIdx.z, h = blockIdx.y;
   const int sub = threadIdx.x & 3;
   // few keys (the 17 support keypoints): the 4-lane key groups would fill a quarter of the block and walk all Lq queries alone;
@@ -261,18 +271,6 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   const int parts = p.Lk <= 16 ? 4 : (p.Lk <= 32 ? 2 : 1);
   const int tpp = 256 / parts, part = threadIdx.x / tpp, tl = threadIdx.x - part * tpp;
   const int j = blockIdx.x * (tpp >> 2) + (tl >> 2);
-  stage_rows(Qs, Q + (long long)n * p.bsq + h * HD, p.ldq, p.Lq);
-  stage_rows(Gs, dO + (long long)n * p.bso + h * HD, p.ldo, p.Lq);
-  for (int r = threadIdx.x; r < p.Lq; r += blockDim.x) {
-    const float* op = O + (long long)n * p.bso + (long long)r * p.ldo + h * HD;
-    const float* gp = dO + (long long)n * p.bso + (long long)r * p.ldo + h * HD;
-    float d = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) d += op[c] * gp[c];
-    Ds[r] = d;
-    Ls[r] = lse[((long long)n * p.H + h) * p.Lq + r];
-  }
-  __syncthreads();
   const bool live = j < p.Lk;
   float k[8], v[8], ak[8], av[8];
 #pragma unroll
@@ -290,17 +288,33 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
   // causal: key j is seen by queries i >= j - offset ; wave-uniform start = min over the wave's keys
   int ibeg = 0;
   if (p.mask_mode == 1) ibeg = max(0, blockIdx.x * (tpp >> 2) + ((tl & ~63) >> 2) - p.causal_offset);
-  for (int i = ibeg + part; i < p.Lq; i += parts) {
-    const float4 q0 = *reinterpret_cast<const float4*>(Qs + i * HD + sub * 8);
-    const float4 q1 = *reinterpret_cast<const float4*>(Qs + i * HD + sub * 8 + 4);
-    const float4 g0 = *reinterpret_cast<const float4*>(Gs + i * HD + sub * 8);
-    const float4 g1 = *reinterpret_cast<const float4*>(Gs + i * HD + sub * 8 + 4);
+  for (int qb = 0; qb < p.Lq; qb += MAXL) {
+  const int qc = min(MAXL, p.Lq - qb);
+  if (qb) __syncthreads();                     // everyone is done with the previous panel
+  stage_rows(Qs, Q + (long long)n * p.bsq + (long long)qb * p.ldq + h * HD, p.ldq, qc);
+  stage_rows(Gs, dO + (long long)n * p.bso + (long long)qb * p.ldo + h * HD, p.ldo, qc);
+  for (int r = threadIdx.x; r < qc; r += blockDim.x) {
+    const float* op = O + (long long)n * p.bso + (long long)(qb + r) * p.ldo + h * HD;
+    const float* gp = dO + (long long)n * p.bso + (long long)(qb + r) * p.ldo + h * HD;
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) d += op[c] * gp[c];
+    Ds[r] = d;
+    Ls[r] = lse[((long long)n * p.H + h) * p.Lq + qb + r];
+  }
+  __syncthreads();
+  for (int i = max(ibeg, qb) + part; i < qb + qc; i += parts) {      // (any split of a panel's queries over the partitions will do)
+    const int ii = i - qb;
+    const float4 q0 = *reinterpret_cast<const float4*>(Qs + ii * HD + sub * 8);
+    const float4 q1 = *reinterpret_cast<const float4*>(Qs + ii * HD + sub * 8 + 4);
+    const float4 g0 = *reinterpret_cast<const float4*>(Gs + ii * HD + sub * 8);
+    const float4 g1 = *reinterpret_cast<const float4*>(Gs + ii * HD + sub * 8 + 4);
     const float s = quad_sum(dot8(k, q0, q1));
     float dp = quad_sum(dot8(v, g0, g1));
     bool masked = !live || keymasked;
     if (p.mask_mode == 1) masked = masked || (j > i + p.causal_offset);
     if (masked) continue;
-    const float pe = __expf(s - Ls[i]);
+    const float pe = __expf(s - Ls[ii]);
     float pd = pe;
     if (p.thresh) {
       const bool keep = cape_keep(seed, step, p.rng_stream, (((uint64_t)n * p.H + h) * p.Lq + i) * p.Lk + j, p.thresh);
@@ -309,9 +323,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     }
     av[0] += pd * g0.x; av[1] += pd * g0.y; av[2] += pd * g0.z; av[3] += pd * g0.w;
     av[4] += pd * g1.x; av[5] += pd * g1.y; av[6] += pd * g1.z; av[7] += pd * g1.w;
-    const float ds = pe * (dp - Ds[i]) * p.scale;
+    const float ds = pe * (dp - Ds[ii]) * p.scale;
     ak[0] += ds * q0.x; ak[1] += ds * q0.y; ak[2] += ds * q0.z; ak[3] += ds * q0.w;
     ak[4] += ds * q1.x; ak[5] += ds * q1.y; ak[6] += ds * q1.z; ak[7] += ds * q1.w;
+  }
   }
   if (parts > 1) {                                               // block-uniform
     __syncthreads();                                             // every partition is done with Qs / Gs
@@ -452,8 +467,8 @@ __global__ void __launch_bounds__(256) attn_softmax_bwd_kernel(const float* __re
 int fill(AttnP& p, long long ldq, long long ldk, long long ldv, long long ldo, const long long* bs, int N, int H, int Lq, int Lk, float scale,
          int mask_mode, int causal_offset, const uint8_t* kpm, float dropout_p, const uint64_t* rng_state,
          uint32_t rng_stream, bool fwd = false) {
-  // the forward tiles its keys and takes any length; the backward kernels stage whole panels
-  CAPE_REQUIRE(Lq >= 1 && Lk >= 1 && (fwd || (Lq <= MAXL && Lk <= MAXL)), "cape_attn: Lq=%d Lk=%d must be in 1..%d", Lq, Lk, MAXL);
+  // forward and backward stage their panels MAXL rows at a time and take any length
+  CAPE_REQUIRE(Lq >= 1 && Lk >= 1, "cape_attn: Lq=%d Lk=%d must be positive", Lq, Lk);
   CAPE_REQUIRE((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0, "cape_attn: row strides must be multiples of 4");
   CAPE_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "cape_attn: bad mask_mode %d", mask_mode);
   CAPE_REQUIRE(mask_mode != 2 || kpm, "cape_attn: key padding mask missing");
@@ -517,10 +532,11 @@ extern "C" int cape_attn_bwd(const float* dO, const float* Q, const float* K, co
   const long long bs[4] = {bsq, bsk, bsv, bso};
   if (fill(p, ldq, ldk, ldv, ldo, bs, N, H, Lq, Lk, scale, mask_mode, causal_offset, kpm, dropout_p, rng_state, rng_stream)) return 1;
   if (raise_lds_limit()) return 1;
-  const size_t sh1 = (size_t)2 * Lk * HD * sizeof(float);
+  const int KC = Lk < MAXL ? Lk : MAXL, QC = Lq < MAXL ? Lq : MAXL;
+  const size_t sh1 = (size_t)2 * KC * HD * sizeof(float);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Lq + ROWS - 1) / ROWS, H, N), dim3(256), sh1, as_stream(stream), dO, Q, K, V,
                      O, lse, dQ, p);
-  size_t sh2 = ((size_t)2 * Lq * HD + 2 * Lq) * sizeof(float);
+  size_t sh2 = ((size_t)2 * QC * HD + 2 * QC) * sizeof(float);
   if (Lk <= 32 && sh2 < 256 * 16 * sizeof(float)) sh2 = 256 * 16 * sizeof(float);      // partition reduction scratch of the few-key form
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Lk + ROWS - 1) / ROWS, H, N), dim3(256), sh2, as_stream(stream), dO, Q, K, V,
                      O, lse, dK, dV, p);

@@ -47,7 +47,7 @@ __global__ void add_n_kernel(const AddNP p, float* o, long long n) {
 // the same with row-strided sources: source j is (rows, cols) with row stride ld[j] (a column block of a wider buffer, e.g. the
 // q part of the decoder's wide [dq | dk | dv] gradient), cols % 4 == 0
 struct AddNRowsP { const float* src[8]; long long ld[8]; int k; };
-__global__ void add_n_rows_kernel(const AddNRowsP p, float* o, long long rows, int cols) {
+__global__ void add_n_rows_kernel(const AddNRowsP p, float* o, long long ldo, long long rows, int cols) {
   const int c4 = cols >> 2;
   GSTRIDE(i, rows * c4) {
     const long long r = i / c4;
@@ -59,7 +59,7 @@ __global__ void add_n_rows_kernel(const AddNRowsP p, float* o, long long rows, i
         const float4 y = *reinterpret_cast<const float4*>(p.src[j] + r * p.ld[j] + c);
         s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
       }
-    *reinterpret_cast<float4*>(o + r * cols + c) = s;
+    *reinterpret_cast<float4*>(o + r * ldo + c) = s;      // (the output may be one of the sources: element-wise read, then write)
   }
 }
 
@@ -324,6 +324,38 @@ __global__ void scale_residual_kernel(const float* __restrict__ x, const float* 
   const long long tot = rows * C;
   GSTRIDE(i, tot) out[i] = x[i] + y[i] * (gamma ? gamma[i % C] : 1.f);
 }
+// d/dx of the exact GELU: Phi(x) + x * phi(x)
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx, long long n) {
+  GSTRIDE(i, n) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+    dx[i] = g[i] * (cdf + v * pdf);
+  }
+}
+// backward of out = x + gamma * y with respect to y and gamma: dy = gamma * g ; dgamma[c] += sum_r g[r][c] * y[r][c].
+// One column per lane (C <= 1024 columns over grid.x), row slabs over grid.y, one atomic per column and block.
+__global__ void __launch_bounds__(256) scale_residual_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                  const float* __restrict__ gamma, float* __restrict__ dy,
+                                                                  float* __restrict__ dgamma, long long rows, int C,
+                                                                  long long rows_per_block) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < C) {
+    const float gm = gamma[col];
+    for (long long r = r0 + w; r < r1; r += 4) {
+      const float gv = g[r * C + col];
+      s += gv * y[r * C + col];
+      dy[r * C + col] = gm * gv;
+    }
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && col < C) atomicAdd(&dgamma[col], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
 __global__ void zero_rows_kernel(float* x, const uint8_t* rowmask, long long rows, int C) {
   const long long tot = rows * C;
   GSTRIDE(i, tot) if (rowmask[i / C]) x[i] = 0.f;
@@ -397,8 +429,8 @@ extern "C" int cape_add_n_f32(const float* const* srcs, int k, float* out, long 
   return 0;
 }
 
-extern "C" int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long rows, int cols,
-                                   cape_stream_t stream) {
+extern "C" int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long ldo, long long rows,
+                                   int cols, cape_stream_t stream) {
   CAPE_REQUIRE(srcs && lds && out && k >= 1 && k <= 8 && rows >= 0 && cols >= 4 && cols % 4 == 0, "cape_add_n_rows_f32: 1..8 sources, cols % 4 == 0");
   if (rows == 0) return 0;
   AddNRowsP p;
@@ -410,8 +442,9 @@ extern "C" int cape_add_n_rows_f32(const float* const* srcs, const long long* ld
     al |= reinterpret_cast<uintptr_t>(p.src[j]);
   }
   CAPE_REQUIRE((al & 15) == 0, "cape_add_n_rows_f32: pointers must be 16-byte aligned");
+  CAPE_REQUIRE(ldo >= cols && ldo % 4 == 0, "cape_add_n_rows_f32: bad output row stride");
   p.k = k;
-  LAUNCH1(add_n_rows_kernel, rows * (cols / 4), 1, p, out, rows, cols);
+  LAUNCH1(add_n_rows_kernel, rows * (cols / 4), 1, p, out, ldo, rows, cols);
   CAPE_LAUNCH_CHECK("cape_add_n_rows_f32");
   return 0;
 }
@@ -421,6 +454,27 @@ extern "C" int cape_gelu_f32(const float* x, float* out, long long n, cape_strea
   if (n == 0) return 0;
   LAUNCH1(gelu_kernel, n, 4, x, out, n);
   CAPE_LAUNCH_CHECK("cape_gelu_f32");
+  return 0;
+}
+
+extern "C" int cape_gelu_bwd_f32(const float* x, const float* g, float* dx, long long n, cape_stream_t stream) {
+  CAPE_REQUIRE(x && g && dx && n >= 0, "cape_gelu_bwd_f32: bad arguments");
+  if (n == 0) return 0;
+  LAUNCH1(gelu_bwd_kernel, n, 4, x, g, dx, n);
+  CAPE_LAUNCH_CHECK("cape_gelu_bwd_f32");
+  return 0;
+}
+
+extern "C" int cape_scale_residual_bwd_f32(const float* g, const float* y, const float* gamma, float* dy, float* dgamma,
+                                           long long rows, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(g && y && gamma && dy && dgamma && rows >= 0 && C > 0, "cape_scale_residual_bwd_f32: bad arguments");
+  if (rows == 0) return 0;
+  long long slabs = (rows + 63) / 64;
+  if (slabs > 256) slabs = 256;
+  const long long rpb = (rows + slabs - 1) / slabs;
+  hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
+                     as_stream(stream), g, y, gamma, dy, dgamma, rows, C, rpb);
+  CAPE_LAUNCH_CHECK("cape_scale_residual_bwd_f32");
   return 0;
 }
 

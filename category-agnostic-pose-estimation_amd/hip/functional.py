@@ -775,6 +775,124 @@ def fanout(x, k):
 
 
 # ------------------------------------------------------------------------------------------------
+# pieces of the bidirectional cross-attention blocks (models/bixattn.py): exact GELU, LayerScale residual, attention cores over
+# [r | v] projections.  Dropout-free (the reference never trains these blocks; the fixtures are taken with every rate at 0)
+# ------------------------------------------------------------------------------------------------
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.gelu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(x, _c(g))
+
+
+def gelu(x):
+    return GeluFn.apply(x)
+
+
+class ScaleResidualFn(torch.autograd.Function):
+    """out = x + gamma * y (gamma per channel, or None = 1; x None = 0)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma):
+        y = _c(y)
+        ctx.has_x = x is not None
+        ctx.save_for_backward(y, gamma)
+        ctx.gref = gamma
+        return ops.scale_residual(_c(x) if x is not None else torch.zeros_like(y), y, gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma = ctx.saved_tensors
+        g = _c(g)
+        dx = g if ctx.has_x else None
+        if gamma is None:
+            return dx, g, None
+        sink = _sink(ctx.gref)
+        dgamma = sink if sink is not None else torch.zeros_like(gamma)
+        dy = ops.scale_residual_bwd(g, y, gamma, dgamma)
+        if sink is not None:
+            Runtime.notify(_param_of(ctx.gref))
+            dgamma = None
+        return dx, dy, dgamma
+
+
+def scale_residual(x, y, gamma=None):
+    return ScaleResidualFn.apply(x, y, gamma)
+
+
+class BiAttnCoreFn(torch.autograd.Function):
+    """Both directions of bixattn.py:52-88 over rv_l = [r_l | v_l] (B, Nl, 2D) and rv_p = [r_p | v_p] (B, Np, 2D):
+        lat = softmax_p(scale r_l r_p^T) v_p      pat = softmax_l(scale r_p r_l^T) v_l
+    Backward: each direction is one pass of the attention backward kernels writing into column blocks of d_rv_l / d_rv_p; the two
+    contributions to d r_l (query of one direction, key of the other) and to d r_p are added in place."""
+
+    @staticmethod
+    def forward(ctx, rv_l, rv_p, nheads, scale):
+        rv_l, rv_p = _c(rv_l), _c(rv_p)
+        B, Nl, D2 = rv_l.shape
+        Np, D = rv_p.shape[1], D2 // 2
+        lat, lse1 = ops.attn_fwd(rv_l[..., :D], rv_p[..., :D], rv_p[..., D:], B, nheads, Nl, Np, scale)
+        pat, lse2 = ops.attn_fwd(rv_p[..., :D], rv_l[..., :D], rv_l[..., D:], B, nheads, Np, Nl, scale)
+        ctx.save_for_backward(rv_l, rv_p, lat, pat, lse1, lse2)
+        ctx.meta = (nheads, scale)
+        return lat, pat
+
+    @staticmethod
+    def backward(ctx, d_lat, d_pat):
+        rv_l, rv_p, lat, pat, lse1, lse2 = ctx.saved_tensors
+        nheads, scale = ctx.meta
+        B, Nl, D2 = rv_l.shape
+        Np, D = rv_p.shape[1], D2 // 2
+        d_l, d_p = torch.empty_like(rv_l), torch.empty_like(rv_p)
+        t_l, t_p = torch.empty_like(rv_l), torch.empty_like(rv_p)     # (only the r halves are used: same row stride as the inputs)
+        ops.attn_bwd(_c(d_lat), rv_l[..., :D], rv_p[..., :D], rv_p[..., D:], lat, lse1, d_l[..., :D], d_p[..., :D], d_p[..., D:],
+                     B, nheads, Nl, Np, scale)
+        ops.attn_bwd(_c(d_pat), rv_p[..., :D], rv_l[..., :D], rv_l[..., D:], pat, lse2, t_p[..., :D], t_l[..., :D], d_l[..., D:],
+                     B, nheads, Np, Nl, scale)
+        ops.add_n_rows([d_l[..., :D], t_l[..., :D]], out=d_l[..., :D])
+        ops.add_n_rows([d_p[..., :D], t_p[..., :D]], out=d_p[..., :D])
+        return d_l, d_p, None, None
+
+
+def bi_attn_core(rv_l, rv_p, nheads, scale):
+    return BiAttnCoreFn.apply(rv_l, rv_p, nheads, float(scale))
+
+
+class AttnKVFn(torch.autograd.Function):
+    """One direction (bixattn.py:90-119): out = softmax(scale r_q r_k^T) v_k with [r_k | v_k] = rv_kv (B, Nk, 2D)."""
+
+    @staticmethod
+    def forward(ctx, r_q, rv_kv, nheads, scale):
+        r_q, rv_kv = _c(r_q), _c(rv_kv)
+        B, Nq, D = r_q.shape
+        Nk = rv_kv.shape[1]
+        out, lse = ops.attn_fwd(r_q, rv_kv[..., :D], rv_kv[..., D:], B, nheads, Nq, Nk, scale)
+        ctx.save_for_backward(r_q, rv_kv, out, lse)
+        ctx.meta = (nheads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        r_q, rv_kv, out, lse = ctx.saved_tensors
+        nheads, scale = ctx.meta
+        B, Nq, D = r_q.shape
+        Nk = rv_kv.shape[1]
+        dq, dkv = torch.empty_like(r_q), torch.empty_like(rv_kv)
+        ops.attn_bwd(_c(d_out), r_q, rv_kv[..., :D], rv_kv[..., D:], out, lse, dq, dkv[..., :D], dkv[..., D:], B, nheads, Nq, Nk, scale)
+        return dq, dkv, None, None
+
+
+def attn_kv(r_q, rv_kv, nheads, scale):
+    return AttnKVFn.apply(r_q, rv_kv, nheads, float(scale))
+
+
+# ------------------------------------------------------------------------------------------------
 # input_proj GroupNorm of all levels, written straight into the flattened token buffer
 # ------------------------------------------------------------------------------------------------
 class LevelGroupNormFn(torch.autograd.Function):

@@ -143,9 +143,11 @@ _SIGS = {
     "cape_add_f32": [P, P, P, LL, P],
     "cape_level_embed_add": [P, P, P, P, I, I, I, I, P],
     "cape_add_n_f32": [POINTER(c_void_p), I, P, LL, P],
-    "cape_add_n_rows_f32": [POINTER(c_void_p), POINTER(c_longlong), I, P, LL, I, P],
+    "cape_add_n_rows_f32": [POINTER(c_void_p), POINTER(c_longlong), I, P, LL, LL, I, P],
     "cape_augment_batch": [P, I, I, I, P, P, P],
     "cape_gelu_f32": [P, P, LL, P],
+    "cape_gelu_bwd_f32": [P, P, P, LL, P],
+    "cape_scale_residual_bwd_f32": [P, P, P, P, P, LL, I, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],
     "cape_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "cape_bn_fold": [P, P, P, P, F, P, P, I, P],

@@ -678,9 +678,19 @@ def augment_batch(items_dev_u8, n, max_pixels, out_size, mean=None, std=None):
     lib.call("cape_augment_batch", _p(items_dev_u8), n, int(max_pixels), int(out_size), _p(mean), _p(std), _stream())
 
 
-def add_n_rows(tensors):
+def _row_ld(t, rows, cols):
+    if t.is_contiguous():
+        return cols
+    # leading dims must walk one uniform row stride: (d0, d1, ..., cols) with stride[i] == stride[i+1] * shape[i+1]
+    st, sh = t.stride(), t.shape
+    assert t.stride(-1) == 1 and all(st[i] == st[i + 1] * sh[i + 1] for i in range(len(sh) - 2)), "add_n_rows: leading dims do not collapse"
+    return st[-2]
+
+
+def add_n_rows(tensors, out=None):
     """Sum of 1..8 tensors of one shape whose last dimension is dense and whose leading dimensions collapse to one row index
-    with a uniform row stride (contiguous tensors, or column blocks of wider contiguous buffers): one pass, no copies."""
+    with a uniform row stride (contiguous tensors, or column blocks of wider contiguous buffers): one pass, no copies.
+    `out` (same shape; may be strided the same way, may be one of the sources) receives the sum; default: a new tensor."""
     k = len(tensors)
     assert 1 <= k <= 8
     shape = tensors[0].shape
@@ -699,10 +709,15 @@ def add_n_rows(tensors):
         else:
             lds.append(cols)
         assert _avail(t) >= (rows - 1) * lds[-1] + cols
-    out = torch.empty(shape, dtype=_F32, device=tensors[0].device)
+    if out is None:
+        out = torch.empty(shape, dtype=_F32, device=tensors[0].device)
+    _chk(out, "add_n_rows.out", contiguous=False)
+    assert out.shape == shape
+    ldo = _row_ld(out, rows, cols)
+    assert _avail(out) >= (rows - 1) * ldo + cols
     arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors])
     ld = (ctypes.c_longlong * k)(*lds)
-    lib.call("cape_add_n_rows_f32", arr, ld, k, _p(out), rows, cols, _stream())
+    lib.call("cape_add_n_rows_f32", arr, ld, k, _p(out), ldo, rows, cols, _stream())
     return out
 
 
@@ -711,6 +726,25 @@ def gelu(x):
     out = torch.empty_like(x)
     lib.call("cape_gelu_f32", _p(x), _p(out), x.numel(), _stream())
     return out
+
+
+def gelu_bwd(x, g):
+    _chk(x, "gelu_bwd.x"); _chk(g, "gelu_bwd.g")
+    assert x.shape == g.shape
+    dx = torch.empty_like(x)
+    lib.call("cape_gelu_bwd_f32", _p(x), _p(g), _p(dx), x.numel(), _stream())
+    return dx
+
+
+def scale_residual_bwd(g, y, gamma, dgamma):
+    """(dy, ) of out = x + gamma * y; dgamma (C,) is accumulated into."""
+    _chk(g, "scale_residual_bwd.g"); _chk(y, "scale_residual_bwd.y"); _chk(gamma, "scale_residual_bwd.gamma")
+    _chk(dgamma, "scale_residual_bwd.dgamma", contiguous=False)
+    C = y.shape[-1]
+    assert g.shape == y.shape and gamma.numel() == C and _avail(dgamma) >= C
+    dy = torch.empty_like(y)
+    lib.call("cape_scale_residual_bwd_f32", _p(g), _p(y), _p(gamma), _p(dy), _p(dgamma), y.numel() // C, C, _stream())
+    return dy
 
 
 def scale_residual(x, y, gamma=None):

@@ -1,9 +1,12 @@
 """Bidirectional cross-attention blocks (reference `models/bixattn.py:5-235`) on the MI355X kernels.
 
 The reference never executes these classes (only the unreachable decoder-layer variant V3 builds them,
-`deformable_transformer_v2.py:894-900`), so they are provided as standalone inference ops with the reference's class
-names, constructor arguments and `state_dict` keys: forward only (eval mode; dropout / drop-path rates must be inactive),
-parity at class level against the reference's own classes (tests/golden/bixattn.npz).
+`deformable_transformer_v2.py:894-900`), so they are provided as standalone ops with the reference's class names,
+constructor arguments and `state_dict` keys, forward AND backward (autograd nodes of hip/functional.py: LayerNorm, Linear,
+exact GELU, LayerScale residual, the two attention directions as one node), parity at class level against the reference's own
+classes: outputs (tests/golden/bixattn.npz) and input / parameter gradients (tests/golden/bixattn_grads.npz).  Training mode is
+accepted while every drop rate is 0 (the fixtures' setting); a non-zero rate in training mode raises -- no dropout kernel is
+wired into these blocks.
 
 One similarity matrix serves both directions in the reference; here each direction is one pass of the tiled
 online-softmax attention kernel (`cape_attn_fwd`, keys staged 256 rows at a time): latents attend over the patches,
@@ -16,20 +19,24 @@ from ..hip import functional as HF
 from ..hip import ops
 
 
-def _need_eval(mod):
-    if mod.training:
-        raise RuntimeError(f"{type(mod).__name__}: inference-only on the MI355X path (call .eval(); the reference never trains it)")
+def _no_active_dropout(mod):
+    """Training mode is fine while nothing would drop: the MI355X blocks carry no dropout / drop-path kernel."""
+    if not mod.training:
+        return
+    for m in mod.modules():
+        if isinstance(m, nn.Dropout) and m.p > 0:
+            raise RuntimeError(f"{type(mod).__name__}: dropout p={m.p} in training mode is not implemented on the MI355X path "
+                               "(the reference never trains these blocks; use rate 0 or .eval())")
+    if getattr(mod, "drop_path", 0.0):
+        raise RuntimeError(f"{type(mod).__name__}: drop_path={mod.drop_path} in training mode is not implemented on the MI355X path")
 
 
 def _ln(x, norm):
-    return ops.add_layernorm_fwd(x.contiguous(), None, norm.weight, norm.bias)[0]
+    return HF.add_layernorm(x, None, norm.weight, norm.bias)
 
 
 def _lin(x, lin):
-    B, N, K = x.shape
-    out = torch.empty(B, N, lin.weight.shape[0], device=x.device, dtype=x.dtype)
-    ops.gemm(x.contiguous(), lin.weight, out, B * N, lin.weight.shape[0], K, bias=lin.bias)
-    return out
+    return HF.linear(x, lin.weight, lin.bias)
 
 
 class LayerScale(nn.Module):
@@ -38,10 +45,13 @@ class LayerScale(nn.Module):
         self.inplace = inplace
         self.gamma = nn.Parameter(init_values * torch.ones(dim))
 
-    @torch.no_grad()
     def forward(self, x):
-        y = ops.scale_residual(torch.zeros_like(x), x.contiguous(), self.gamma)
-        return x.copy_(y) if self.inplace else y
+        y = HF.scale_residual(None, x, self.gamma)
+        if self.inplace:                                  # x.mul_(gamma) of the reference: only meaningful outside autograd
+            with torch.no_grad():
+                x.copy_(y)
+            return x
+        return y
 
 
 class Mlp(nn.Module):
@@ -57,9 +67,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
         self.drop2 = nn.Dropout(drop)
 
-    @torch.no_grad()
     def forward(self, x):
-        return _lin(ops.gelu(_lin(x, self.fc1)), self.fc2)
+        _no_active_dropout(self)
+        return _lin(HF.gelu(_lin(x, self.fc1)), self.fc2)
 
 
 class _AttnBase(nn.Module):
@@ -70,9 +80,6 @@ class _AttnBase(nn.Module):
         self.num_heads, self.dim_attn = num_heads, dim_attn
         self.scale = (dim_attn // num_heads) ** -0.5
 
-    def _attend(self, r_q, r_k, v_k):
-        B, Lq, Lk = r_q.shape[0], r_q.shape[1], r_k.shape[1]
-        return ops.attn_fwd(r_q, r_k, v_k, B, self.num_heads, Lq, Lk, self.scale)[0]
 
 
 class BiXAttn(_AttnBase):
@@ -85,13 +92,11 @@ class BiXAttn(_AttnBase):
         self.proj_lat, self.proj_drop_lat = nn.Linear(dim_attn, dim_lat), nn.Dropout(proj_drop)
         self.proj_pat, self.proj_drop_pat = nn.Linear(dim_attn, dim_pat), nn.Dropout(proj_drop)
 
-    @torch.no_grad()
     def forward(self, x_latents, x_patches):
-        _need_eval(self)
-        D = self.dim_attn
+        _no_active_dropout(self)
         rv_l, rv_p = _lin(x_latents, self.rv_latents), _lin(x_patches, self.rv_patches)     # (B, N, 2D): [r | v]
-        lat = self._attend(rv_l[..., :D], rv_p[..., :D], rv_p[..., D:])                    # softmax over patches
-        pat = self._attend(rv_p[..., :D], rv_l[..., :D], rv_l[..., D:])                    # softmax over latents
+        # lat: softmax over the patches; pat: softmax over the latents (one autograd node for both directions)
+        lat, pat = HF.bi_attn_core(rv_l, rv_p, self.num_heads, self.scale)
         return _lin(lat, self.proj_lat), _lin(pat, self.proj_pat)
 
 
@@ -104,12 +109,10 @@ class CrossAttentionOneSided(_AttnBase):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj_lat, self.proj_drop_lat = nn.Linear(dim_attn, dim_lat), nn.Dropout(proj_drop)
 
-    @torch.no_grad()
     def forward(self, x_latents, x_patches):
-        _need_eval(self)
-        D = self.dim_attn
+        _no_active_dropout(self)
         r_l, rv_p = _lin(x_latents, self.r_latents), _lin(x_patches, self.rv_patches)
-        return _lin(self._attend(r_l, rv_p[..., :D], rv_p[..., D:]), self.proj_lat)
+        return _lin(HF.attn_kv(r_l, rv_p, self.num_heads, self.scale), self.proj_lat)
 
 
 def _ls(dim, init_values):
@@ -117,7 +120,7 @@ def _ls(dim, init_values):
 
 
 def _res(x, y, ls):
-    return ops.scale_residual(x.contiguous(), y.contiguous(), ls.gamma if isinstance(ls, LayerScale) else None)
+    return HF.scale_residual(x, y, ls.gamma if isinstance(ls, LayerScale) else None)
 
 
 class BiXAttnBlock(nn.Module):
@@ -139,9 +142,8 @@ class BiXAttnBlock(nn.Module):
         self.mlp_pat = Mlp(in_features=dim_pat, hidden_features=int(dim_pat * pat_mlp_ratio), act_layer=act_layer, drop=drop)
         self.ls2_pat = _ls(dim_pat, init_values)
 
-    @torch.no_grad()
     def forward(self, x_latents, x_patches):
-        _need_eval(self)
+        _no_active_dropout(self)
         a_l, a_p = self.attn(_ln(x_latents, self.norm1_lat), _ln(x_patches, self.norm1_pat))
         x_latents = _res(x_latents, a_l, self.ls1_lat)
         x_latents = _res(x_latents, self.mlp_lat(_ln(x_latents, self.norm2_lat)), self.ls2_lat)
@@ -166,9 +168,8 @@ class CAOneSidedBlock(nn.Module):
         self.mlp_lat = Mlp(in_features=dim_lat, hidden_features=int(dim_lat * lat_mlp_ratio), act_layer=act_layer, drop=drop)
         self.ls2_lat = _ls(dim_lat, init_values)
 
-    @torch.no_grad()
     def forward(self, x_latents, x_patches):
-        _need_eval(self)
+        _no_active_dropout(self)
         a_l = self.attn(_ln(x_latents, self.norm1_lat), _ln(x_patches, self.norm1_pat))
         x_latents = _res(x_latents, a_l, self.ls1_lat)
         x_latents = _res(x_latents, self.mlp_lat(_ln(x_latents, self.norm2_lat)), self.ls2_lat)

@@ -363,13 +363,20 @@ int cape_level_embed_add(const float* base, const float* level_embed, const int*
 /* out = srcs[0] + ... + srcs[k-1] (k <= 8 host-array of device pointers, n elements each): the gradient fan-in of a tensor with
  * several consumers in one pass (what autograd's InputBuffer does with k-1 `at::add` launches). */
 int cape_add_n_f32(const float* const* srcs, int k, float* out, long long n, cape_stream_t stream);
-/* the same for (rows, cols) sources with row strides lds[j] (cols % 4 == 0): a summand may be a column block of a wider buffer */
-int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long rows, int cols,
+/* the same for (rows, cols) sources with row strides lds[j] (cols % 4 == 0): a summand may be a column block of a wider buffer,
+ * and so may the output (row stride ldo; `out` may coincide with a source: in-place accumulation) */
+int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long ldo, long long rows, int cols,
                         cape_stream_t stream);
 int cape_gelu_f32(const float* x, float* out, long long n, cape_stream_t stream);
 /* out[r][c] = x[r][c] + y[r][c] * gamma[c] (gamma may be NULL): residual behind LayerScale (models/bixattn.py:5-31,135-141) */
 int cape_scale_residual_f32(const float* x, const float* y, const float* gamma, float* out, long long rows, int C,
                             cape_stream_t stream);
+/* backward of the exact GELU (bixattn.py Mlp): dx = g * (Phi(x) + x phi(x)) */
+int cape_gelu_bwd_f32(const float* x, const float* g, float* dx, long long n, cape_stream_t stream);
+/* backward of out = x + gamma * y (LayerScale residual, bixattn.py:11-19) w.r.t. y and gamma: dy = gamma * g,
+ * dgamma[c] += sum_r g[r][c] y[r][c] (dgamma is accumulated into: zero or hold a running gradient) */
+int cape_scale_residual_bwd_f32(const float* g, const float* y, const float* gamma, float* dy, float* dgamma, long long rows, int C,
+                                cape_stream_t stream);
 /* NCHW (N,C,H,W) -> NHWC with channel padding to Cp (zeros) */
 int cape_nchw_to_nhwc(const float* x, float* out, int N, int C, int H, int W, int Cp, cape_stream_t stream);
 /* FrozenBatchNorm fold: scale = w * rsqrt(rv + eps), shift = b - rm * scale  (backbone.py:32-40) */

@@ -48,6 +48,39 @@ def main():
     np.savez_compressed(os.path.join(OUT, "bixattn.npz"), bi_lat=ol.numpy(), bi_pat=op[:, ::5].numpy(), bi0_lat=ol0.numpy(),
                         bi0_pat=op0[:, ::5].numpy(), one_lat=oo.numpy())
     print("wrote bixattn.npz")
+    grads(blk, blk0, one, lat, pat)
+
+
+def grads(blk, blk0, one, lat, pat):
+    """Round 3: backward of the same three blocks (train mode, every drop rate 0 -- the reference's dropouts are then the
+    identity), loss = <out_lat, c_lat> + <out_pat, c_pat> with seeded cotangents (re-created by the tests): input gradients in
+    full (patches: every 5th row) and, per parameter, the gradient's L2 norm plus its first 8 elements."""
+    rng = np.random.Generator(np.random.PCG64(32))
+    c_lat = torch.from_numpy(rng.standard_normal((2, 24, 256)).astype(np.float32))
+    c_pat = torch.from_numpy(rng.standard_normal((2, 280, 256)).astype(np.float32))
+    out = {}
+    for name, m in (("bi", blk), ("bi0", blk0), ("one", one)):
+        m.train()
+        m.zero_grad()
+        xl, xp = lat.clone().requires_grad_(True), pat.clone().requires_grad_(True)
+        ol, op = m(xl, xp)
+        loss = (ol * c_lat).sum() + ((op * c_pat).sum() if op is not None else 0.0)
+        loss.backward()
+        out[name + "_dlat"] = xl.grad.numpy()
+        out[name + "_dpat"] = xp.grad[:, ::5].numpy()
+        names, norms, heads = [], [], []
+        for k, p_ in m.named_parameters():
+            if p_.grad is None:
+                continue
+            names.append(k)
+            norms.append(float(p_.grad.norm()))
+            heads.append(p_.grad.reshape(-1)[:8].numpy().copy())
+        out[name + "_pnames"] = np.array(names)
+        out[name + "_pnorms"] = np.array(norms, dtype=np.float64)
+        out[name + "_pheads"] = np.stack(heads)
+        m.eval()
+    np.savez_compressed(os.path.join(OUT, "bixattn_grads.npz"), **out)
+    print("wrote bixattn_grads.npz")
 
 
 if __name__ == "__main__":

@@ -292,8 +292,43 @@ def test_bixattn_blocks_against_reference_golden(golden_dir):
     assert (ol.cpu() - t(d["bi0_lat"])).abs().max() <= 4 * tol and (op.cpu()[:, ::5] - t(d["bi0_pat"])).abs().max() <= 4 * tol
     oo, none = fill(CAOneSidedBlock(256, 256, 256, 8, init_values=0.1), "bixattn.one")(lat, pat)
     assert none is None and (oo.cpu() - t(d["one_lat"])).abs().max() <= tol
-    with pytest.raises(RuntimeError):
-        BiXAttnBlock(256, 256, 256, 8).cuda().train()(lat, pat)
+    with pytest.raises(RuntimeError):                       # an active drop rate has no kernel on this path
+        BiXAttnBlock(256, 256, 256, 8, drop=0.1).cuda().train()(lat, pat)
+
+
+def test_bixattn_blocks_backward_against_reference_golden(golden_dir):
+    """Row a14, backward: input gradients and every parameter gradient (norm + first 8 elements) of the three blocks against the
+    reference's own classes under autograd (oracle/make_golden_bixattn.py::grads; train mode, all drop rates 0)."""
+    from oracle import procweights
+    from oracle.make_golden_bixattn import inputs
+    from cape_amd.models.bixattn import BiXAttnBlock, CAOneSidedBlock
+    d = np.load(os.path.join(golden_dir, "bixattn_grads.npz"))
+    rng = np.random.Generator(np.random.PCG64(32))
+    c_lat = torch.from_numpy(rng.standard_normal((2, 24, 256)).astype(np.float32)).cuda()
+    c_pat = torch.from_numpy(rng.standard_normal((2, 280, 256)).astype(np.float32)).cuda()
+    lat0, pat0 = inputs()
+
+    def fill(mod, prefix):
+        mod.load_state_dict({k: procweights.tensor_for(prefix + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()}, strict=True)
+        return mod.cuda().train()
+
+    rel = 2e-5 if _precision() == "f32" else 3e-4
+    for name, mod in (("bi", fill(BiXAttnBlock(256, 256, 256, 8, init_values=0.1), "bixattn.bi")),
+                      ("bi0", fill(BiXAttnBlock(256, 256, 256, 8, rv_bias=True, init_values=None), "bixattn.bi0")),
+                      ("one", fill(CAOneSidedBlock(256, 256, 256, 8, init_values=0.1), "bixattn.one"))):
+        xl, xp = lat0.cuda().requires_grad_(True), pat0.cuda().requires_grad_(True)
+        ol, op = mod(xl, xp)
+        loss = (ol * c_lat).sum() + ((op * c_pat).sum() if op is not None else 0.0)
+        loss.backward()
+        for got, key in ((xl.grad, name + "_dlat"), (xp.grad[:, ::5], name + "_dpat")):
+            ref = t(d[key])
+            assert (got.cpu() - ref).abs().max() <= rel * max(1.0, float(ref.abs().max())), (name, key)
+        grads = {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+        assert sorted(grads) == sorted(str(k) for k in d[name + "_pnames"])
+        for k, norm, head in zip(d[name + "_pnames"], d[name + "_pnorms"], d[name + "_pheads"]):
+            g = grads[str(k)]
+            assert abs(float(g.norm()) - norm) <= 5 * rel * max(norm, 1e-3), (name, k, float(g.norm()), norm)
+            assert (g.reshape(-1)[:8].cpu() - t(head)).abs().max() <= 5 * rel * max(1.0, float(g.abs().max())), (name, k)
 
 
 def _precision():

@@ -481,7 +481,8 @@ def _attn_ref(q, k, v, scale, mask):
     return (F.softmax(s, -1) @ vh).transpose(1, 2).reshape(N, Lq, C)
 
 
-@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 70, 17, 2), (2, 9, 9, 0), (2, 1, 37, 0), (1, 130, 130, 1)])
+@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 70, 17, 2), (2, 9, 9, 0), (2, 1, 37, 0), (1, 130, 130, 1),
+                                          (2, 24, 280, 0), (1, 300, 290, 1), (2, 280, 24, 2)])        # panels beyond 256 rows
 def test_attention_fwd_bwd(N, Lq, Lk, mode):
     H = 8
     big_q, big_k, big_v = rnd(N, Lq, 768, seed=1), rnd(N, Lk, 768, seed=2), rnd(N, Lk, 768, seed=3)

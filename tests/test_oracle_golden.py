@@ -203,6 +203,25 @@ def test_bixattn_blocks_match_reference(golden_dir):
     oo = cape_ref.ca_one_sided_block(lat, pat, sd_for("bixattn.one", block_spec(False, True, True)), "bixattn.one")
     assert (oo - torch.from_numpy(d["one_lat"])).abs().max() <= 1e-5
 
+    # round 3: the same restatement under autograd against the reference's gradients (bixattn_grads.npz)
+    g = np.load(os.path.join(golden_dir, "bixattn_grads.npz"))
+    rng = np.random.Generator(np.random.PCG64(32))
+    c_lat = torch.from_numpy(rng.standard_normal((2, 24, 256)).astype(np.float32))
+    c_pat = torch.from_numpy(rng.standard_normal((2, 280, 256)).astype(np.float32))
+    for name, spec, fn in (("bi", block_spec(False, True, False), cape_ref.bixattn_block),
+                           ("bi0", block_spec(True, False, False), cape_ref.bixattn_block),
+                           ("one", block_spec(False, True, True), cape_ref.ca_one_sided_block)):
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd_for("bixattn." + name, spec).items()}
+        xl, xp = lat.clone().requires_grad_(True), pat.clone().requires_grad_(True)
+        out = fn(xl, xp, sd, "bixattn." + name)
+        ol, op = out if isinstance(out, tuple) else (out, None)
+        ((ol * c_lat).sum() + ((op * c_pat).sum() if op is not None else 0.0)).backward()
+        assert (xl.grad - torch.from_numpy(g[name + "_dlat"])).abs().max() <= 2e-5 * max(1.0, float(np.abs(g[name + "_dlat"]).max()))
+        assert (xp.grad[:, ::5] - torch.from_numpy(g[name + "_dpat"])).abs().max() <= 2e-5 * max(1.0, float(np.abs(g[name + "_dpat"]).max()))
+        for k, norm in zip(g[name + "_pnames"], g[name + "_pnorms"]):
+            got = float(sd["bixattn." + name + "." + str(k)].grad.norm())
+            assert abs(got - norm) <= 1e-4 * max(norm, 1e-3), (name, k, got, norm)
+
 
 # ------------------------------------------------------------------------------------------------
 # round-2 fixtures (oracle/make_golden_r2.py): BASELINE configs[3] / configs[4] geometries and the training loop
