@@ -355,10 +355,14 @@ def _group_ok(d):
             and (d.b_mode == 3 or d.ldb % 4 == 0) and max(d.lda, d.ldb, d.ldc) < (1 << 31))
 
 
+_GROUP_BIG_MN = int(os.environ.get("CAPE_GROUP_BIG_MN", str(64 * 1024)))      # tuning switch
+
+
 def group_tile(M, N, K):
-    """Output tile edge of a queued weight gradient: 128 for big outputs over deep contractions (the FFN and 3x3-conv weights:
-    halved L2 -> L1 operand traffic per flop, profiles/r02_wgrad_sweep.txt), else 64."""
-    return 128 if (M >= 128 and N >= 128 and M * N >= 256 * 1024 and K >= 4096) else 64
+    """Output tile edge of a queued weight gradient: 128 for outputs of >= 256 x 256 over deep contractions (halved L2 -> L1 operand
+    traffic per flop, profiles/r02_wgrad_sweep.txt; as a launch of its own a 256 x 256 x 43520 product preferred 64-tiles -- 4 big
+    tiles x 64 k-splits of atomics -- but inside a group of ~10 products the splits stay at 8-16: step 25.54 -> 25.34 ms), else 64."""
+    return 128 if (M >= 128 and N >= 128 and M * N >= _GROUP_BIG_MN and K >= 4096) else 64
 
 
 def plan_group_splits(shapes, tile):

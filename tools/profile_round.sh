@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for one round: kernel stats of the bench command, then the two PMC passes for the GEMM family's HBM
-# traffic (separate passes, no trace domains beside --kernel-trace).  Usage: bash tools/profile_round.sh <tag> ; output
+# traffic (separate passes, no trace domains beside --kernel-trace).  Usage: bash tools/profile_round.sh <dir> [<profiles tag, e.g. r03>] ; output
 # under gpurun_out/<tag>/, summaries to be copied into profiles/.
 set -o pipefail
 tag=${1:-prof}; root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
@@ -14,4 +14,8 @@ python3 tools/gemm_traffic.py $out/fetch $out/write $out/gemm_traffic.json
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv
 # keep the merge-back small: the per-dispatch traces are large
 find $out/stats $out/fetch $out/write -name "*.csv" -size +4M -delete
-head -25 $out/kernel_stats.csv
+# the bench line of the same tree on the same box (with the roofline leg; profiles/<tag>_gemm_traffic.json must already hold this
+# tree's traffic for `traffic_stale: false`, so the driver copies it first)
+if [ -n "$2" ]; then cp $out/gemm_traffic.json profiles/$2_gemm_traffic.json; fi
+python3 bench.py --steps 20 --warmup 3 > $out/bench_line.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
+head -12 $out/kernel_stats.csv | cut -c1-200
