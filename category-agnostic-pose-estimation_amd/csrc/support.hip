@@ -115,6 +115,25 @@ __global__ void gcn_bwd_kernel(const float* __restrict__ d_out, const float* __r
   }
 }
 
+// key-padding mask glue of the support encoder (geometric_support_encoder.py:201-220) in one launch: one wave per graph.
+//   mask (N, P) u8, non-zero = ignore.  A graph whose keypoints are ALL masked would give softmax rows of -inf: keypoint 0 is
+//   unmasked for the attention (kpm) and the graph's output rows are zeroed afterwards (zero).
+//   kpm[n][p]  = mask[n][p], except kpm[n][0] = 0 when every keypoint of graph n is masked
+//   zero[n][p] = all-masked(n)  (| mask[n][p] when pad_rows: the nested-tensor fast path of nn.TransformerEncoder returns 0 at
+//                padded positions)
+__global__ void __launch_bounds__(64) support_masks_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ kpm,
+                                                           uint8_t* __restrict__ zero, int N, int P, int pad_rows) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  bool any_valid = false;
+  for (int p_ = lane; p_ < P; p_ += 64) any_valid = any_valid || (mask[(long long)n * P + p_] == 0);
+  const bool all_masked = __ballot(any_valid) == 0ull;
+  for (int p_ = lane; p_ < P; p_ += 64) {
+    const uint8_t m = mask[(long long)n * P + p_] != 0;
+    kpm[(long long)n * P + p_] = (p_ == 0 && all_masked) ? 0 : m;
+    zero[(long long)n * P + p_] = (all_masked || (pad_rows && m)) ? 1 : 0;
+  }
+}
+
 }  // namespace
 
 extern "C" int cape_support_embed_fwd(const float* coords, const float* W0, const float* b0, const float* pe1d,
@@ -164,5 +183,13 @@ extern "C" int cape_gcn_aggregate_bwd(const float* d_out, const float* out, cons
   if (N <= 0) return 0;
   hipLaunchKernelGGL(gcn_bwd_kernel, dim3((unsigned)((long long)N * P)), dim3(256), 0, as_stream(stream), d_out, out, adj, d_y, P, C);
   CAPE_LAUNCH_CHECK("cape_gcn_aggregate_bwd");
+  return 0;
+}
+
+extern "C" int cape_support_masks(const uint8_t* mask, uint8_t* kpm, uint8_t* zero, int N, int P, int pad_rows, cape_stream_t stream) {
+  CAPE_REQUIRE(mask && kpm && zero && N >= 0 && P > 0, "cape_support_masks: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(support_masks_kernel, dim3((unsigned)N), dim3(64), 0, as_stream(stream), mask, kpm, zero, N, P, pad_rows);
+  CAPE_LAUNCH_CHECK("cape_support_masks");
   return 0;
 }

@@ -146,6 +146,7 @@ _SIGS = {
     "cape_add_n_rows_f32": [POINTER(c_void_p), POINTER(c_longlong), I, P, LL, LL, I, P],
     "cape_augment_batch": [P, I, I, I, P, P, P],
     "cape_gelu_f32": [P, P, LL, P],
+    "cape_support_masks": [P, P, P, I, I, I, P],
     "cape_gelu_bwd_f32": [P, P, P, LL, P],
     "cape_scale_residual_bwd_f32": [P, P, P, P, P, LL, I, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],

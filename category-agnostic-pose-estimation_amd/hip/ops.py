@@ -977,6 +977,22 @@ def gcn_aggregate_bwd(d_out, out, adj, N, P, C=256):
     return d_y
 
 
+def as_u8(mask):
+    """A bool mask as uint8 without a conversion kernel (both are one byte per element)."""
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
+def support_masks(mask_u8, pad_rows=False):
+    """(kpm, zero) of the support encoder's key-padding glue (cape_support_masks): mask (N, P) uint8, non-zero = ignore."""
+    _chk(mask_u8, "support_masks.mask", dtype=torch.uint8)
+    N, P = mask_u8.shape
+    kpm, zero = torch.empty_like(mask_u8), torch.empty_like(mask_u8)
+    lib.call("cape_support_masks", _p(mask_u8), _p(kpm), _p(zero), N, P, int(pad_rows), _stream())
+    return kpm, zero
+
+
 def zero_rows(x, rowmask_u8):
     _chk(x, "zero_rows.x"); _chk(rowmask_u8, "zero_rows.mask", dtype=torch.uint8)
     C = x.shape[-1]

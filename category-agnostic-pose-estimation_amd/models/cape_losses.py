@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from ..hip import functional as HF
+from ..hip import ops
 
 
 class CAPESetCriterion(nn.Module):
@@ -34,7 +35,7 @@ class CAPESetCriterion(nn.Module):
         NL = logits.shape[0]
         dev = logits.device
         labels = targets["token_labels"].to(dev)
-        vis = targets["visibility_mask"].to(dev).to(torch.uint8) if "visibility_mask" in targets else \
+        vis = ops.as_u8(targets["visibility_mask"].to(dev)) if "visibility_mask" in targets else \
             torch.ones_like(labels, dtype=torch.uint8)
         w_ce, w_l1 = float(self.weight_dict["loss_ce"]), float(self.weight_dict["loss_coords"])
         total, per = HF.cape_loss(logits, coords, labels, vis, targets["target_seq"].to(dev),

@@ -214,7 +214,7 @@ class TransformerDecoder(nn.Module):
             support_features = getattr(self, "support_features", None)
         if support_mask is None:
             support_mask = getattr(self, "support_mask", None)
-        kpm = support_mask.to(torch.uint8).contiguous() if (support_features is not None and support_mask is not None) else None
+        kpm = ops.as_u8(support_mask) if (support_features is not None and support_mask is not None) else None
         output = self._seq_embed(seq11=seq_kwargs["seq11"], seq12=seq_kwargs["seq12"], seq21=seq_kwargs["seq21"],
                                  seq22=seq_kwargs["seq22"], delta_x1=seq_kwargs["delta_x1"], delta_x2=seq_kwargs["delta_x2"],
                                  delta_y1=seq_kwargs["delta_y1"], delta_y2=seq_kwargs["delta_y2"])

@@ -44,23 +44,26 @@ class GeometricSupportEncoder(nn.Module):
         if num_pts > 100:
             raise RuntimeError("more keypoints than PositionalEncoding1D.max_len=100")
         support_mask = support_mask.bool()
+        mask_u8 = ops.as_u8(support_mask)
         m0, m2 = self.coord_mlp[0], self.coord_mlp[2]
         h, pe = HF.support_embed(support_coords, m0.weight, m0.bias, self.sequence_pos_encoding.pe[0].contiguous())
         x = HF.linear(h, m2.weight, m2.bias, residual=pe)                  # coord_emb + pos_emb + seq_pe
         if self.use_gcn_preenc and self.gcn_layers is not None:
             if skeleton_edges is None:
                 skeleton_edges = [[] for _ in range(bs)]
-            adj = adj_from_skeleton(num_pts, skeleton_edges, support_mask, support_coords.device)
+            adj = adj_from_skeleton(num_pts, skeleton_edges, mask_u8, support_coords.device)
             for g in self.gcn_layers:
                 x = g(x, adj)
-        # all-masked guard (geometric_support_encoder.py:201-220): unmask keypoint 0, zero the output rows
-        all_masked = support_mask.all(dim=1)
-        mask = support_mask.clone()
-        mask[:, 0] &= ~all_masked
-        # nn.TransformerEncoder's nested-tensor fast path: eval, no grad, mask left-aligned for the whole batch
-        valid = (~mask).to(torch.int8)
-        fast = (not self.training) and (not torch.is_grad_enabled()) and bool(((valid[:, 1:] - valid[:, :-1]) <= 0).all())
-        kpm = mask.to(torch.uint8).contiguous()
+        # all-masked guard (geometric_support_encoder.py:201-220): unmask keypoint 0 for the attention, zero the output rows -- one
+        # launch (cape_support_masks) instead of nine framework operators.
+        # nn.TransformerEncoder's nested-tensor fast path: eval, no grad, mask left-aligned for the whole batch (a host decision:
+        # only taken outside autograd, where the reference takes it too)
+        fast = False
+        if (not self.training) and (not torch.is_grad_enabled()):
+            valid = (~support_mask).to(torch.int8)
+            valid[:, 0] |= support_mask.all(dim=1).to(torch.int8)          # (keypoint 0 of a fully masked graph counts as valid)
+            fast = bool(((valid[:, 1:] - valid[:, :-1]) <= 0).all())
+        kpm, zero_u8 = ops.support_masks(mask_u8, pad_rows=fast)
         p = self.dropout_p if self.training else 0.0
         for li, layer in enumerate(self.transformer_encoder.layers):
             sa, st = layer.self_attn, self._streams[li]
@@ -72,13 +75,10 @@ class GeometricSupportEncoder(nn.Module):
             hdn = HF.ffn(x_f, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, dropout_p=p,
                          rng_stream=st[2])
             x = HF.add_layernorm(x_r, hdn, layer.norm2.weight, layer.norm2.bias, dropout_p=p, rng_stream=st[3])
-        zero = all_masked[:, None].expand(bs, num_pts)
-        if fast:
-            zero = zero | mask
         # the reference branches on `.any()` (geometric_support_encoder.py:218): that is a device->host sync per step, which
         # stops the host from enqueueing ahead of the GPU; the row-zeroing kernel is a no-op when no row is flagged, so it runs
         # unconditionally instead
-        x = HF.zero_rows(x, zero.reshape(-1).to(torch.uint8).contiguous())
+        x = HF.zero_rows(x, zero_u8.reshape(-1))
         return x
 
     def __repr__(self):

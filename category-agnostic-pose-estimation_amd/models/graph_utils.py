@@ -41,7 +41,7 @@ def adj_from_skeleton(num_pts, skeleton, mask, device="cuda"):
     """skeleton: list (len bs) of [[i, j], ...] 0-indexed, or a DeviceSkeleton; mask (bs, num_pts) bool, True = ignore.
     Returns (bs, 2, num_pts, num_pts): [diag(~mask), row-normalised symmetric adjacency]."""
     if isinstance(skeleton, DeviceSkeleton):
-        return ops.adjacency(skeleton.edges.contiguous(), skeleton.start, mask.to(torch.uint8).contiguous(), len(skeleton), num_pts)
+        return ops.adjacency(skeleton.edges.contiguous(), skeleton.start, ops.as_u8(mask), len(skeleton), num_pts)
     bs = len(skeleton)
     flat, start = [], [0]
     for edges in skeleton:
@@ -50,7 +50,7 @@ def adj_from_skeleton(num_pts, skeleton, mask, device="cuda"):
         start.append(len(flat))
     dev = mask.device if isinstance(mask, torch.Tensor) else torch.device(device)
     edges_t, start_t = _edge_tables(flat, start, dev)[:2]
-    return ops.adjacency(edges_t, start_t, mask.to(torch.uint8).contiguous(), bs, num_pts)
+    return ops.adjacency(edges_t, start_t, ops.as_u8(mask), bs, num_pts)
 
 
 _EDGE_TABLES = {}

@@ -446,6 +446,10 @@ int cape_support_embed_bwd(const float* d_h, const float* h, const float* coords
 int cape_adjacency(const int* edges, const int* edge_start, const uint8_t* mask, float* adj, int N, int P,
                    cape_stream_t stream);
 /* GCN aggregate: out[n,w,c] = relu( sum_k sum_v adj[n,k,v,w] * y[n,v,k*C+c] )  (graph_utils.py:157-186) */
+/* key-padding glue of GeometricSupportEncoder.forward (geometric_support_encoder.py:201-220) in one launch: mask (N, P) u8,
+ * non-zero = ignore -> kpm = mask with keypoint 0 unmasked where a graph is fully masked, zero = rows to be zeroed afterwards
+ * (fully masked graphs; with pad_rows also every masked row: the nested-tensor fast path of nn.TransformerEncoder). */
+int cape_support_masks(const uint8_t* mask, uint8_t* kpm, uint8_t* zero, int N, int P, int pad_rows, cape_stream_t stream);
 int cape_gcn_aggregate_fwd(const float* y, const float* adj, float* out, int N, int P, int C,
                            cape_stream_t stream);
 /* d_y[n,v,k*C+c] = sum_w adj[n,k,v,w] * d_out[n,w,c] * (out[n,w,c] > 0) */
