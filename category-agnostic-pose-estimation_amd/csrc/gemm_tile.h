@@ -121,6 +121,48 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
     }
   }
 
+  // conv gather fast paths (round 3).  The general forms below recompute (tap, channel) of every k index with integer divisions per
+  // thread and k-tile and rebuild a 64-bit pixel address per row -- 35-75 % more time than the dense product of the same shape
+  // (tools/conv_bench.py), in a loop that is bound by instruction issue.  When the channel count is a multiple of the 32-deep
+  // k-tile, a k-tile lies inside ONE filter tap: (kh, kw, channel offset) is a wave-uniform state advanced once per k-tile, a row
+  // keeps the element offset of its centre pixel, and a load address is that offset plus a uniform tap offset (one 64-bit add,
+  // two compares).  Same loads, same arithmetic, bitwise identical results.
+  constexpr bool A_CONV = (AMODE == 2 || AMODE == 3);
+  const bool a_fast = A_CONV && KFULL && (AMODE == 2 ? (p.cC % BK == 0) : (p.cO % BK == 0 && p.cStride == 1));
+  long long a_base[NA];
+  int cv_kh = 0, cv_kw = 0, cv_c0 = 0;                         // tap and channel offset of the k-tile the NEXT load_tiles call reads
+  if constexpr (A_CONV) {
+    if (a_fast) {
+      const int CC = (AMODE == 2) ? p.cC : p.cO;
+      const int k0 = kt_begin * BK;
+      const int tap = k0 / CC;
+      cv_c0 = k0 - tap * CC;
+      cv_kh = tap / p.cKW;
+      cv_kw = tap - cv_kh * p.cKW;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const long long nn = max(a_n[j], 0);
+        a_base[j] = (AMODE == 2) ? ((nn * p.cH + a_y[j]) * p.cW + a_x[j]) * p.cC + 4 * a_kc
+                                 : ((nn * p.cOH + a_y[j]) * p.cOW + a_x[j]) * p.cO + 4 * a_kc;
+      }
+    }
+  }
+  // BMODE 2 (dgrad weight [k = tap*O + o][n = c], always with AMODE 3): per-thread constant part of the address
+  int b_koff[NB];
+  if constexpr (BMODE == 2) {
+    const int ncol = min(n0 + 4 * b_mc, p.N - 4);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int kofs = PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j;
+      b_koff[j] = kofs * (p.cKH * p.cKW) * p.cC + ncol;
+    }
+  }
+  // BMODE 3 (wgrad im2col, k = output position): power-of-two output extents turn the two divisions per load into shifts
+  int b3_lw = -1, b3_lh = 0;
+  if constexpr (BMODE == 3) {
+    if ((p.cOW & (p.cOW - 1)) == 0 && (p.cOH & (p.cOH - 1)) == 0) { b3_lw = __ffs(p.cOW) - 1; b3_lh = __ffs(p.cOH) - 1; }
+  }
+
   // register stages: DEPTH k-tiles of both operands in flight between global memory and the LDS store.  Measured on
   // MI355X: DEPTH 3 (64x64) / 2 (128x128) is 5-10 % SLOWER than 1 on every shape of tools/gemm_bench.py -- the loop is
   // bound by instruction issue (VALU split + LDS traffic), not by memory latency, and the extra live registers cost more
@@ -175,6 +217,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         }
       }
     } else if constexpr (AMODE == 2) {
+      if (a_fast) {
+        const long long tap_off = ((long long)cv_kh * p.cW + cv_kw) * p.cC + cv_c0;          // uniform
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int iy = a_y[j] + cv_kh, ix = a_x[j] + cv_kw;
+          const bool ok = (a_n[j] >= 0) && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+          const float4 v = *reinterpret_cast<const float4*>(p.A + (ok ? a_base[j] + tap_off : (long long)(4 * a_kc)));
+          ra[sl][j] = ok ? v : zero4();
+        }
+      } else {
       const int k = kbase + 4 * a_kc;
       const int kq = (KFULL || k < p.K) ? k : 0;
       const int tap = kq / p.cC, c = kq - tap * p.cC;
@@ -185,6 +237,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         const bool ok = (a_n[j] >= 0) && (KFULL || k < p.K) && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
         const int nn = max(a_n[j], 0), yy = min(max(iy, 0), p.cH - 1), xx = min(max(ix, 0), p.cW - 1);
         const float4 v = *reinterpret_cast<const float4*>(p.A + (((long long)nn * p.cH + yy) * p.cW + xx) * p.cC + c);
+        ra[sl][j] = ok ? v : zero4();
+      }
+      }
+    } else if (a_fast) {  // AMODE == 3, stride 1, O % 32 == 0
+      const long long tap_off = cv_c0 - ((long long)cv_kh * p.cOW + cv_kw) * p.cO;           // uniform
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int ty = a_y[j] - cv_kh, tx = a_x[j] - cv_kw;
+        const bool ok = (a_n[j] >= 0) && (unsigned)ty < (unsigned)p.cOH && (unsigned)tx < (unsigned)p.cOW;
+        const float4 v = *reinterpret_cast<const float4*>(p.A + (ok ? a_base[j] + tap_off : (long long)(4 * a_kc)));
         ra[sl][j] = ok ? v : zero4();
       }
     } else {  // AMODE == 3: dgrad gather of dY (N, OH, OW, O); k = tap*O + o
@@ -246,6 +308,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
           rb[sl][j] = (k < p.K && vn) ? ldg4(p.B + (long long)k * p.ldb + ncol, vn) : zero4();
         }
       }
+    } else if (BMODE == 2 && a_fast) {  // the k-tile lies in one tap: (o0 * taps + tap) * C is uniform, the rest per-thread constant
+      const long long tb = ((long long)cv_c0 * (p.cKH * p.cKW) + cv_kh * p.cKW + cv_kw) * p.cC;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[sl][j] = *reinterpret_cast<const float4*>(p.B + tb + b_koff[j]);
     } else if constexpr (BMODE == 2) {  // weight (O, KH, KW, C) read as [k = tap*O + o][n = c]
       const int ncol = min(n0 + 4 * b_mc, p.N - 4);
       const int taps = p.cKH * p.cKW;
@@ -268,15 +334,31 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         const int k = kbase + (PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j);
         const bool kin = KFULL || k < p.K;
         const int kq = kin ? k : 0;
-        const int ox = kq % p.cOW;
-        const int tq = kq / p.cOW;
-        const int oy = tq % p.cOH;
-        const int n = tq / p.cOH;
+        int ox, oy, n;
+        if (b3_lw >= 0) {
+          ox = kq & (p.cOW - 1);
+          oy = (kq >> b3_lw) & (p.cOH - 1);
+          n = kq >> (b3_lw + b3_lh);
+        } else {
+          ox = kq % p.cOW;
+          const int tq = kq / p.cOW;
+          oy = tq % p.cOH;
+          n = tq / p.cOH;
+        }
         const int iy = oy * p.cStride - p.cPad + kh, ix = ox * p.cStride - p.cPad + kw;
         const bool ok = kin && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
         const int yy = min(max(iy, 0), p.cH - 1), xx = min(max(ix, 0), p.cW - 1);
         const float4 v = *reinterpret_cast<const float4*>(p.B + (((long long)n * p.cH + yy) * p.cW + xx) * p.cC + c);
         rb[sl][j] = ok ? v : zero4();
+      }
+    }
+    if constexpr (A_CONV) {                                       // the next call reads the next k-tile (calls come in k order)
+      if (a_fast) {
+        cv_c0 += BK;
+        if (cv_c0 == ((AMODE == 2) ? p.cC : p.cO)) {
+          cv_c0 = 0;
+          if (++cv_kw == p.cKW) { cv_kw = 0; ++cv_kh; }
+        }
       }
     }
   };

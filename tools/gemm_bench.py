@@ -24,6 +24,8 @@ if os.environ.get("GEMM_BENCH_WGRAD"):          # k-split sweep of the weight-gr
     SHAPES = [(m, n, k, 1, 1, sk) for (m, n, k) in [(256, 256, 43520), (1024, 256, 43520), (256, 1024, 43520), (128, 256, 43520),
                                                      (256, 256, 6400), (1024, 256, 6400), (256, 1024, 6400), (256, 256, 544)]
               for sk in (1, 4, 8, 16, 24, 32, 64, 128) if k // sk >= 128]
+if os.environ.get("GEMM_BENCH_SHAPES"):          # "M,N,K,am,bm,sk;M,N,K,am,bm,sk;..."
+    SHAPES = [tuple(int(v) for v in item.split(",")) for item in os.environ["GEMM_BENCH_SHAPES"].split(";") if item]
 if os.environ.get("GEMM_BENCH_RS_ONLY"):
     SHAPES = [s for s in SHAPES if s[3] == 0 and s[5] == 1 and s[2] in (64, 128, 256)]
 
