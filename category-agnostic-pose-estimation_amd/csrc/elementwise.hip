@@ -63,6 +63,25 @@ __global__ void add_n_rows_kernel(const AddNRowsP p, float* o, long long ldo, lo
   }
 }
 
+struct Cls4 { const float* c[4]; };
+__global__ void interleave2x2_kernel(const Cls4 cls, const float* acc, float* __restrict__ out, int N, int H, int W, int C) {
+  const int c4n = C >> 2, H2 = H >> 1, W2 = W >> 1;
+  const long long tot = (long long)N * H * W * c4n;
+  GSTRIDE(i, tot) {
+    const int c = (int)(i % c4n) * 4;
+    long long pix = i / c4n;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    const float* src = cls.c[(y & 1) * 2 + (x & 1)];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src) v = *reinterpret_cast<const float4*>(src + (((long long)n * H2 + (y >> 1)) * W2 + (x >> 1)) * C + c);
+    const long long o = (((long long)n * H + y) * W + x) * C + c;
+    if (acc) { const float4 a = *reinterpret_cast<const float4*>(acc + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    *reinterpret_cast<float4*>(out + o) = v;
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* x, float* o, int N, int C, int H, int W, int Cp) {
   const long long tot = (long long)N * H * W * Cp;
   GSTRIDE(i, tot) {
@@ -446,6 +465,19 @@ extern "C" int cape_add_n_rows_f32(const float* const* srcs, const long long* ld
   p.k = k;
   LAUNCH1(add_n_rows_kernel, rows * (cols / 4), 1, p, out, ldo, rows, cols);
   CAPE_LAUNCH_CHECK("cape_add_n_rows_f32");
+  return 0;
+}
+
+extern "C" int cape_interleave2x2_f32(const float* const* cls, const float* acc, float* out, int N, int H, int W, int C, cape_stream_t stream) {
+  CAPE_REQUIRE(cls && out && N >= 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && C > 0 && (C % 4) == 0,
+               "cape_interleave2x2_f32: even H, W and C %% 4 == 0");
+  if (N == 0) return 0;
+  Cls4 c4;
+  uintptr_t al = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(acc);
+  for (int k = 0; k < 4; ++k) { c4.c[k] = cls[k]; al |= reinterpret_cast<uintptr_t>(cls[k]); }
+  CAPE_REQUIRE((al & 15) == 0, "cape_interleave2x2_f32: pointers must be 16-byte aligned");
+  LAUNCH1(interleave2x2_kernel, (long long)N * H * W * (C / 4), 1, c4, acc, out, N, H, W, C);
+  CAPE_LAUNCH_CHECK("cape_interleave2x2_f32");
   return 0;
 }
 

@@ -13,7 +13,7 @@ int cape_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cape_last_error(void) { return g_err; }
-extern "C" int cape_abi_version(void) { return 10; }
+extern "C" int cape_abi_version(void) { return 11; }
 
 __global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
 extern "C" int cape_rng_advance(uint64_t* rng_state, cape_stream_t stream) {

@@ -144,6 +144,16 @@ extern "C" int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream) {
   p.bdiv = d->batch_div > 0 ? d->batch_div : 1;
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
   p.res_cols = d->res_cols; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
+  if (d->cKHp > 0) {
+    CAPE_REQUIRE(d->a_mode == 3 && d->b_mode == 2 && d->cStride == 1 && d->cO % 32 == 0 && d->K % 32 == 0 && d->cKWp > 0 &&
+                     d->cTapHS >= 1 && d->cTapWS >= 1 && d->cTapH0 >= 0 && d->cTapW0 >= 0 &&
+                     d->cTapH0 + (d->cKH - 1) * d->cTapHS < d->cKHp && d->cTapW0 + (d->cKW - 1) * d->cTapWS < d->cKWp,
+                 "cape_gemm_f32: tap sub-lattice needs conv-dgrad modes, stride 1, O %% 32 == 0 and taps inside the physical filter");
+    p.cPadX = d->cPadX; p.cKHp = d->cKHp; p.cKWp = d->cKWp;
+    p.cTapH0 = d->cTapH0; p.cTapHS = d->cTapHS; p.cTapW0 = d->cTapW0; p.cTapWS = d->cTapWS;
+  } else {
+    p.cPadX = d->cPad; p.cKHp = d->cKH; p.cKWp = d->cKW; p.cTapH0 = 0; p.cTapHS = 1; p.cTapW0 = 0; p.cTapWS = 1;
+  }
   CAPE_REQUIRE(d->res_cols >= 0 && d->res_cols % 32 == 0, "cape_gemm_f32: res_cols must be a non-negative multiple of 32");
   if (d->batch > 1)
     CAPE_REQUIRE(d->batch <= 65535 && d->split_k == 1 && !d->scale && !d->residual && !d->mask_src && !d->colsum_out &&

@@ -54,6 +54,8 @@ struct GemmP {
   int single;                    // bf16x3 kernels only: 1 = one bf16 MFMA per product (hi x hi; precision 2, the measured-only AMP leg)
   int res_cols;                  // 0: residual on every column; else (multiple of 32) on columns < res_cols only
   long long sBias0, sBias1;      // per-batch offsets of `bias`
+  // conv-dgrad over a sub-lattice of taps (cape_gemm_desc): column padding, physical filter extent, tap origin / stride
+  int cPadX, cKHp, cKWp, cTapH0, cTapHS, cTapW0, cTapWS;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

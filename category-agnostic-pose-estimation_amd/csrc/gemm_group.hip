@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupArgs g) {
   p.A = q.A; p.lda = q.lda; p.B = q.B; p.ldb = q.ldb; p.C = q.C; p.ldc = q.ldc;
   p.cN = q.cN; p.cH = q.cH; p.cW = q.cW; p.cC = q.cC; p.cKH = q.cKH; p.cKW = q.cKW;
   p.cStride = q.cStride; p.cPad = q.cPad; p.cOH = q.cOH; p.cOW = q.cOW; p.cO = q.cO;
+  p.cPadX = q.cPad; p.cKHp = q.cKH; p.cKWp = q.cKW; p.cTapH0 = 0; p.cTapHS = 1; p.cTapW0 = 0; p.cTapWS = 1;
   p.scale = nullptr; p.bias = nullptr; p.residual = nullptr; p.ldr = 0;
   p.relu = 0; p.accumulate = 1; p.split_k = q.split_k;
   p.colsum_out = q.colsum_out;

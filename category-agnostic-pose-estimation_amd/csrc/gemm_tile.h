@@ -114,7 +114,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         const int y = tq % RH;
         a_n[j] = tq / RH;
         if (AMODE == 2) { a_y[j] = y * p.cStride - p.cPad; a_x[j] = x * p.cStride - p.cPad; }
-        else { a_y[j] = y + p.cPad; a_x[j] = x + p.cPad; }
+        else { a_y[j] = y + p.cPad; a_x[j] = x + p.cPadX; }
       } else {
         a_n[j] = -1; a_y[j] = 0; a_x[j] = 0;
       }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int kofs = PREC ? 2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1) : b_k0 + B_KSTEP * j;
-      b_koff[j] = kofs * (p.cKH * p.cKW) * p.cC + ncol;
+      b_koff[j] = kofs * (p.cKHp * p.cKWp) * p.cC + ncol;       // (physical taps per output channel)
     }
   }
   // BMODE 3 (wgrad im2col, k = output position): power-of-two output extents turn the two divisions per load into shifts
@@ -309,7 +309,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
         }
       }
     } else if (BMODE == 2 && a_fast) {  // the k-tile lies in one tap: (o0 * taps + tap) * C is uniform, the rest per-thread constant
-      const long long tb = ((long long)cv_c0 * (p.cKH * p.cKW) + cv_kh * p.cKW + cv_kw) * p.cC;
+      const long long tb = ((long long)cv_c0 * (p.cKHp * p.cKWp) + (p.cTapH0 + cv_kh * p.cTapHS) * p.cKWp + p.cTapW0 + cv_kw * p.cTapWS) * p.cC;
 #pragma unroll
       for (int j = 0; j < NB; ++j) rb[sl][j] = *reinterpret_cast<const float4*>(p.B + tb + b_koff[j]);
     } else if constexpr (BMODE == 2) {  // weight (O, KH, KW, C) read as [k = tap*O + o][n = c]

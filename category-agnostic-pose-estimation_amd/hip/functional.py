@@ -523,6 +523,8 @@ class ConvFn(torch.autograd.Function):
             dx = acc_dx if acc_dx is not None else torch.empty(N, H, W, C, dtype=torch.float32, device=dy.device)
             if dense:
                 ops.gemm(dpre, wp, dx, M, C, O, a_mode=0, b_mode=1, accumulate=acc_dx is not None)
+            elif _dgrad_stride2_ok(geom):
+                _dgrad_stride2(dpre, wp, geom, dx, acc_dx)
             else:
                 sk = ops.pick_split_k(N * H * W, C, KH * KW * O)
                 sk = sk if sk >= 4 else 1
@@ -563,6 +565,49 @@ class ConvFn(torch.autograd.Function):
             dshift = torch.zeros(O, dtype=torch.float32, device=dy.device)
             ops.colsum(src_s, M, O, dshift)
         return dx, dw, None, dshift, dres, None, None, None, None
+
+
+_DGRAD_S2 = os.environ.get("CAPE_DGRAD_S2_CLASSES", "1") == "1"
+
+
+def _dgrad_stride2_ok(geom):
+    N, H, W, C, KH, KW, stride, pad, OH, OW, O = geom
+    return (_DGRAD_S2 and stride == 2 and H % 2 == 0 and W % 2 == 0 and OH * 2 == H and OW * 2 == W and O % 32 == 0 and C % 4 == 0
+            and (KH, KW, pad) in ((3, 3, 1), (1, 1, 0)))
+
+
+def _dgrad_stride2(dpre, wp, geom, dx, acc_dx):
+    """Data gradient of a stride-2 convolution (3x3 / pad 1, or 1x1) by input-parity classes.  As one gather launch over the
+    full-resolution grid 3 of 4 (pixel, tap) pairs multiply structural zeros (a tap reaches a pixel only when the parities fit).
+    The pixels (2y' + py, 2x' + px) of one class see a fixed subset of the taps and their gradient is a STRIDE-1 data gradient on
+    the half-resolution grid: rows py = 1 use taps kh in {0, 2} with padding 1, rows py = 0 the tap kh = 1 with padding 0 (same
+    for columns): 4 + 2 + 2 + 1 = 9 taps over 4 pixels instead of 36.  The four compact results go back onto the grid (and onto a
+    gradient that already exists there: the shortcut branch's) in one pass.  1x1 / stride 2: only the (even, even) class is
+    non-zero and it is a dense product."""
+    N, H, W, C, KH, KW, stride, pad, OH, OW, O = geom
+    H2, W2 = H // 2, W // 2
+    Mc = N * H2 * W2
+    dev = dpre.device
+    classes = [None] * 4
+    if KH == 1:
+        c00 = torch.empty(N, H2, W2, C, dtype=torch.float32, device=dev)
+        ops.gemm(dpre, wp, c00, Mc, C, O, a_mode=0, b_mode=1)
+        classes[0] = c00
+    else:
+        for py in (0, 1):
+            for px in (0, 1):
+                kh_n, kw_n = (2 if py else 1), (2 if px else 1)
+                sub_geom = (N, H2, W2, C, kh_n, kw_n, 1, (1 if py else 0), OH, OW, O)
+                sub = ((1 if px else 0), KH, KW, (0 if py else 1), 2, (0 if px else 1), 2)
+                K = kh_n * kw_n * O
+                buf = torch.empty(N, H2, W2, C, dtype=torch.float32, device=dev)
+                sk = ops.pick_split_k(Mc, C, K)
+                sk = sk if sk >= 4 else 1
+                if sk > 1:
+                    buf.zero_()
+                ops.gemm(dpre, wp, buf, Mc, C, K, a_mode=3, b_mode=2, conv=sub_geom, conv_sub=sub, split_k=sk, accumulate=sk > 1)
+                classes[py * 2 + px] = buf
+    ops.interleave2x2(classes, acc_dx, dx)
 
 
 def _relu_bwd_noscale(dy, y, relu, want_res):

@@ -45,6 +45,7 @@ class GemmDesc(ctypes.Structure):
         ("batch", c_int), ("batch_div", c_int), ("sA0", c_longlong), ("sA1", c_longlong), ("sB0", c_longlong), ("sB1", c_longlong),
         ("sC0", c_longlong), ("sC1", c_longlong),
         ("res_cols", c_int), ("sBias0", c_longlong), ("sBias1", c_longlong),
+        ("cPadX", c_int), ("cKHp", c_int), ("cKWp", c_int), ("cTapH0", c_int), ("cTapHS", c_int), ("cTapW0", c_int), ("cTapWS", c_int),
     ]
 
 
@@ -147,6 +148,7 @@ _SIGS = {
     "cape_augment_batch": [P, I, I, I, P, P, P],
     "cape_gelu_f32": [P, P, LL, P],
     "cape_support_masks": [P, P, P, I, I, I, P],
+    "cape_interleave2x2_f32": [POINTER(c_void_p), P, P, I, I, I, I, P],
     "cape_gelu_bwd_f32": [P, P, P, LL, P],
     "cape_scale_residual_bwd_f32": [P, P, P, P, P, LL, I, P],
     "cape_scale_residual_f32": [P, P, P, P, LL, I, P],

@@ -264,7 +264,7 @@ class PackedWeights:
 
 def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bias=None, scale=None, residual=None,
          ldr=None, relu=False, accumulate=False, split_k=1, dropout_p=0.0, rng=None, rng_stream=0, conv=None,
-         colsum_out=None, packed=None, mask_src=None, mask_scale=1.0, batch=None, res_cols=0, bias_strides=None):
+         colsum_out=None, packed=None, mask_src=None, mask_scale=1.0, batch=None, res_cols=0, bias_strides=None, conv_sub=None):
     """packed: the B operand as fragment-ordered bf16 planes (PackedWeights / cape_pack_weights); looked up automatically when B
     is a parameter (or a view of one) and the product is one the register-stationary kernel takes."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
@@ -277,6 +277,10 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.ldc = ldc if ldc is not None else N
     if conv is not None:
         (d.cN, d.cH, d.cW, d.cC, d.cKH, d.cKW, d.cStride, d.cPad, d.cOH, d.cOW, d.cO) = conv
+        if conv_sub is not None:          # conv-dgrad over a sub-lattice of the physical filter's taps (cape_gemm_desc, ABI 11)
+            (d.cPadX, d.cKHp, d.cKWp, d.cTapH0, d.cTapHS, d.cTapW0, d.cTapWS) = conv_sub
+            assert a_mode == 3 and b_mode == 2 and _avail(B) >= d.cO * d.cKHp * d.cKWp * d.cC
+            assert _avail(A) >= d.cN * d.cOH * d.cOW * d.cO and _avail(C) >= d.cN * d.cH * d.cW * d.cC
     d.scale = scale.data_ptr() if scale is not None else None
     d.bias = bias.data_ptr() if bias is not None else None
     d.residual = residual.data_ptr() if residual is not None else None
@@ -729,6 +733,20 @@ def gelu(x):
     _chk(x, "gelu.x")
     out = torch.empty_like(x)
     lib.call("cape_gelu_f32", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
+def interleave2x2(classes, acc, out):
+    """out (N, H, W, C) = (acc or 0) + the four (N, H/2, W/2, C) parity classes [(even,even), (even,odd), (odd,even), (odd,odd)]
+    (None = zeros) put back on the full grid (cape_interleave2x2_f32)."""
+    _chk(out, "interleave2x2.out"); _chk(acc, "interleave2x2.acc")
+    N, H, W, C = out.shape
+    assert len(classes) == 4 and H % 2 == 0 and W % 2 == 0 and C % 4 == 0 and (acc is None or acc.shape == out.shape)
+    for c in classes:
+        _chk(c, "interleave2x2.class")
+        assert c is None or c.numel() == N * (H // 2) * (W // 2) * C
+    arr = (ctypes.c_void_p * 4)(*[c.data_ptr() if c is not None else None for c in classes])
+    lib.call("cape_interleave2x2_f32", arr, _p(acc), _p(out), N, H, W, C, _stream())
     return out
 
 

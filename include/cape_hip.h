@@ -102,6 +102,13 @@ typedef struct {
      `+ query_pos` on the q columns only (deformable_transformer_v2.py:323-331).  sBias0 / sBias1: per-batch offsets of `bias`
      for batched launches (the three in_proj blocks of nn.MultiheadAttention as one batch-3 launch). */
   int res_cols; long long sBias0, sBias1;
+  /* round 3 (ABI 11), conv-dgrad (a_mode 3 / b_mode 2, stride 1, O % 32 == 0) over a SUB-LATTICE of filter taps.  A stride-2
+     convolution's data gradient falls into four input-parity classes; each is a stride-1 data gradient on the half-resolution
+     grid whose taps are a strided subset of the physical filter (3x3, pad 1: {0,2} for odd rows / columns, {1} for even ones):
+     cKH / cKW = taps of the class, cPad / cPadX = its row / column padding, and tap (kh', kw') reads the physical filter tap
+     (cTapH0 + kh' * cTapHS, cTapW0 + kw' * cTapWS) of a (cKHp x cKWp) filter.  cKHp == 0: the filter is cKH x cKW as given
+     and cPadX = cPad (every earlier caller).  The whole gradient does 2.25 / 9 of the multiplications of the one-launch form. */
+  int cPadX, cKHp, cKWp, cTapH0, cTapHS, cTapW0, cTapWS;
 } cape_gemm_desc;
 
 int cape_gemm_f32(const cape_gemm_desc* d, cape_stream_t stream);
@@ -365,6 +372,10 @@ int cape_level_embed_add(const float* base, const float* level_embed, const int*
 int cape_add_n_f32(const float* const* srcs, int k, float* out, long long n, cape_stream_t stream);
 /* the same for (rows, cols) sources with row strides lds[j] (cols % 4 == 0): a summand may be a column block of a wider buffer,
  * and so may the output (row stride ldo; `out` may coincide with a source: in-place accumulation) */
+/* out[n][y][x][:] = (acc ? acc[n][y][x][:] : 0) + cls[(y & 1) * 2 + (x & 1)][n][y >> 1][x >> 1][:] for NHWC tensors (H, W even): the
+ * four input-parity classes of a stride-2 convolution's data gradient (cape_gemm_desc, sub-lattice fields) back on the full grid;
+ * a NULL class contributes zeros (1x1 stride-2: only the (even, even) class exists); `acc` may be `out` (in place). */
+int cape_interleave2x2_f32(const float* const* cls, const float* acc, float* out, int N, int H, int W, int C, cape_stream_t stream);
 int cape_add_n_rows_f32(const float* const* srcs, const long long* lds, int k, float* out, long long ldo, long long rows, int cols,
                         cape_stream_t stream);
 int cape_gelu_f32(const float* x, float* out, long long n, cape_stream_t stream);

@@ -28,7 +28,7 @@ def test_binding_covers_header():
 
 
 def test_abi_version_and_error_string():
-    assert lib.abi_version() == 10
+    assert lib.abi_version() == 11
     assert isinstance(lib.last_error(), str)
 
 

@@ -202,6 +202,30 @@ def test_conv_node_k_split_path(N, H, W, C, O, k, stride, pad, res):
     close(wn.grad, w.grad, tol=2e-4, name="conv node wgrad")
 
 
+@pytest.mark.parametrize("N,H,W,C,O,k,pad,acc", [(2, 16, 16, 64, 64, 3, 1, False), (3, 8, 12, 128, 96, 3, 1, True), (2, 16, 16, 64, 128, 1, 0, False),
+                                                 (1, 8, 8, 512, 512, 3, 1, True), (2, 6, 10, 32, 64, 1, 0, True)])
+def test_conv_stride2_dgrad_by_parity_classes(N, H, W, C, O, k, pad, acc):
+    """Data gradient of a stride-2 convolution as four stride-1 data gradients over tap sub-lattices on the half-resolution grid
+    (hip/functional._dgrad_stride2, cape_gemm_desc sub-lattice fields, cape_interleave2x2_f32) against torch and against the
+    one-launch gather form; with an existing gradient to accumulate onto (the bottleneck's shortcut branch)."""
+    from cape_amd.hip import functional as HF
+    x, w, geom, OH, OW = _conv_case(N, H, W, C, O, k, 2, pad)
+    x.requires_grad_(True)
+    g = rnd(N, O, OH, OW, seed=9)
+    F.conv2d(x, w, stride=2, padding=pad).backward(g)
+    wn = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    gn = g.permute(0, 2, 3, 1).contiguous().to(DEV)
+    assert HF._dgrad_stride2_ok(geom)
+    base = rnd(N, H, W, C, seed=11).to(DEV) if acc else None
+    dx = base.clone() if acc else torch.empty(N, H, W, C, device=DEV)
+    HF._dgrad_stride2(gn, wn, geom, dx, dx if acc else None)
+    ref = x.grad.permute(0, 2, 3, 1) + (base.cpu() if acc else 0.0)
+    close(dx, ref, tol=2e-4, name="stride-2 dgrad by classes")
+    one = torch.empty(N * H * W, C, device=DEV)
+    ops.gemm(gn, wn, one, N * H * W, C, k * k * O, a_mode=3, b_mode=2, conv=geom)
+    close(dx - (base if acc else 0.0), one.view(N, H, W, C), tol=2e-5, name="classes vs one gather launch")
+
+
 # ---- fragment-packed weights of the register-stationary kernel (cape_pack_weights, ops.PackedWeights) ----
 @pytest.mark.parametrize("M,N,K,bm", [(5000, 256, 256, 0), (700, 384, 256, 1), (6400, 1024, 256, 0), (333, 100, 128, 1), (4097, 64, 64, 0),
                                       (6400, 70, 256, 0), (400, 70, 256, 0), (129, 33, 64, 1)])
