@@ -254,21 +254,28 @@ __global__ void query_sine_fwd_kernel(const float* ref, const float* dim_t, floa
   }
 }
 
+// one wave per row (4 rows per block, no barrier, no LDS): lane l owns channels l, l + 64 (x axis) and l + 128, l + 192 (y axis)
 __global__ void __launch_bounds__(256) query_sine_bwd_kernel(const float* d_out, const float* ref, const float* dim_t,
                                                               float* d_ref, int accumulate, long long R) {
-  __shared__ float part[4];
-  const long long r = blockIdx.x;
-  const int c = threadIdx.x;
-  const int a = c >> 7, k = c & 127;
-  const float sc = 6.283185307179586f / dim_t[k];
-  const float v = ref[r * 2 + a] * 6.283185307179586f / dim_t[k];
-  const float g = d_out[r * 256 + c] * ((k & 1) ? -sinf(v) : cosf(v)) * sc;
-  const float s = wave_sum(g);
-  if ((c & 63) == 0) part[c >> 6] = s;
-  __syncthreads();
-  if (c < 2) {
-    const float t = part[2 * c] + part[2 * c + 1];
-    if (accumulate) d_ref[r * 2 + c] += t; else d_ref[r * 2 + c] = t;
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;                                            // wave-uniform
+  const float rx = ref[r * 2], ry = ref[r * 2 + 1];
+  float gx = 0.f, gy = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int k = lane + 64 * q;                                 // channel inside an axis: 0..127
+    const float dt = dim_t[k];
+    const float sc = 6.283185307179586f / dt;
+    const float vx = rx * 6.283185307179586f / dt, vy = ry * 6.283185307179586f / dt;
+    gx += d_out[r * 256 + k] * ((k & 1) ? -sinf(vx) : cosf(vx)) * sc;
+    gy += d_out[r * 256 + 128 + k] * ((k & 1) ? -sinf(vy) : cosf(vy)) * sc;
+  }
+  gx = wave_sum(gx);
+  gy = wave_sum(gy);
+  if (lane == 0) {
+    if (accumulate) { d_ref[r * 2] += gx; d_ref[r * 2 + 1] += gy; }
+    else { d_ref[r * 2] = gx; d_ref[r * 2 + 1] = gy; }
   }
 }
 
@@ -622,7 +629,7 @@ extern "C" int cape_query_sine_bwd(const float* d_out, const float* ref, const f
                                    long long R, cape_stream_t stream) {
   CAPE_REQUIRE(d_out && ref && dim_t && d_ref && R < (1ll << 31), "cape_query_sine_bwd: bad arguments");
   if (R == 0) return 0;
-  hipLaunchKernelGGL(query_sine_bwd_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), d_out, ref, dim_t, d_ref,
+  hipLaunchKernelGGL(query_sine_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream), d_out, ref, dim_t, d_ref,
                      accumulate, R);
   CAPE_LAUNCH_CHECK("cape_query_sine_bwd");
   return 0;

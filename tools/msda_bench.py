@@ -33,7 +33,7 @@ def main():
         torch.cuda.synchronize()
         print(f"N={N} Lq={Lq} forward: {e0.elapsed_time(e1) / 20 * 1e3:9.1f} us", flush=True)
         for form in ("atomic", "f64", "fx"):
-            for need_ref in (False,):
+            for need_ref in (False, True):
                 for _ in range(3):
                     ops.msda_bwd(go, value, offw, ref, geo, N, Lq, need_ref_grad=need_ref, form=form)
                 torch.cuda.synchronize()
@@ -44,7 +44,7 @@ def main():
                     ops.msda_bwd(go, value, offw, ref, geo, N, Lq, need_ref_grad=need_ref, form=form)
                 e1.record()
                 torch.cuda.synchronize()
-                print(f"N={N} Lq={Lq} form={form}: {e0.elapsed_time(e1) / it * 1e3:9.1f} us", flush=True)
+                print(f"N={N} Lq={Lq} form={form} d_ref={need_ref}: {e0.elapsed_time(e1) / it * 1e3:9.1f} us", flush=True)
 
 
 if __name__ == "__main__":
