@@ -60,6 +60,32 @@ struct GemmP {
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// [k][mn] bf16 image of an mn-contiguous GEMM operand (32 k rows of W = 64 or 128 elements), consumed by ds_read_b64_tr_b16 (gfx950:
+// a 16-lane group reads 4 rows x 16 columns and every lane receives one COLUMN -- 4 consecutive k of its mn).  Byte offset of the
+// 16-byte chunk `chunk` of row k.  No padding: the chunks of a row are XOR-swizzled by the row so that the 4 rows x 64 bytes a
+// 32-lane half reads at once fall on 64 distinct banks (W = 128: rows are 64 banks apart, chunk ^= 4 (k & 3); W = 64: rows are
+// 32 banks apart, chunk ^= 4 ((k >> 1) & 1)).
+template <int W>
+__device__ __forceinline__ int tr_off(int k, int chunk) {
+  static_assert(W == 64 || W == 128, "tile widths of the family");
+  const int mask = (W == 128) ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
+  return k * (W * 2) + ((chunk ^ mask) << 4);
+}
+typedef short tr_s4 __attribute__((ext_vector_type(4)));
+// 8 consecutive k of the lane's column: two transposed reads 4 rows (`rows4` bytes) apart
+__device__ __forceinline__ bf16x8 tr_read8(const char* p, int rows4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const tr_s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_s4 __attribute__((address_space(3)))*)(p));
+  const tr_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_s4 __attribute__((address_space(3)))*)(p + rows4));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+#else
+  (void)p; (void)rows4;
+  return bf16x8{};
+#endif
+}
+
 constexpr int BK = 32;
 
 // gemm_rs.hip: register-stationary weights (dense A, K in {64, 128, 256}, bf16x3), persistent over 64-row units

@@ -401,20 +401,17 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
           *reinterpret_cast<uint2*>(Ah + o) = make_uint2(h0, h1);
           *reinterpret_cast<uint2*>(Al + o) = make_uint2(l0, l1);
         }
-      } else {                       // rows k, k+1 of 4 consecutive m: "pair-major" plane [k/2][m] of 32-bit (k, k+1)
-                                     // words -> one conflict-free 16-byte store per plane (the [m][k] image would
-                                     // put the 16 lanes of a store on 2 banks)
-        unsigned* Ah32 = reinterpret_cast<unsigned*>(Ah);
+      } else {                       // 4 consecutive m of one k row: the plane is the plain [k][m] image (rows of BM bf16, 16-byte
+                                     // chunks XOR-swizzled by the row, see tr_off) that ds_read_b64_tr_b16 turns into fragments
+        char* Ahb = reinterpret_cast<char*>(Ah);
 #pragma unroll
-        for (int jj = 0; jj < NA / 2; ++jj) {
-          unsigned h[4], l[4];
-          split2(ra[sl][2 * jj].x, ra[sl][2 * jj + 1].x, h[0], l[0]);
-          split2(ra[sl][2 * jj].y, ra[sl][2 * jj + 1].y, h[1], l[1]);
-          split2(ra[sl][2 * jj].z, ra[sl][2 * jj + 1].z, h[2], l[2]);
-          split2(ra[sl][2 * jj].w, ra[sl][2 * jj + 1].w, h[3], l[3]);
-          const int o = (a_k0 + A_KSTEP * jj) * PMA_LD + 4 * a_mc;
-          *reinterpret_cast<uint4*>(Ah32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
-          *reinterpret_cast<uint4*>(Ah32 + A_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
+        for (int j = 0; j < NA; ++j) {
+          unsigned h0, l0, h1, l1;
+          split2(ra[sl][j].x, ra[sl][j].y, h0, l0);
+          split2(ra[sl][j].z, ra[sl][j].w, h1, l1);
+          const int o = tr_off<BM>(2 * (a_k0 + A_KSTEP * (j >> 1)) + (j & 1), a_mc >> 1) + 8 * (a_mc & 1);
+          *reinterpret_cast<uint2*>(Ahb + o) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(Ahb + 2 * A_PL + o) = make_uint2(l0, l1);
         }
       }
       if constexpr (B_KC) {
@@ -428,17 +425,15 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
           *reinterpret_cast<uint2*>(Bl + o) = make_uint2(l0, l1);
         }
       } else {
-        unsigned* Bh32 = reinterpret_cast<unsigned*>(Bh);
+        char* Bhb = reinterpret_cast<char*>(Bh);
 #pragma unroll
-        for (int jj = 0; jj < NB / 2; ++jj) {
-          unsigned h[4], l[4];
-          split2(rb[sl][2 * jj].x, rb[sl][2 * jj + 1].x, h[0], l[0]);
-          split2(rb[sl][2 * jj].y, rb[sl][2 * jj + 1].y, h[1], l[1]);
-          split2(rb[sl][2 * jj].z, rb[sl][2 * jj + 1].z, h[2], l[2]);
-          split2(rb[sl][2 * jj].w, rb[sl][2 * jj + 1].w, h[3], l[3]);
-          const int o = (b_k0 + B_KSTEP * jj) * PMB_LD + 4 * b_mc;
-          *reinterpret_cast<uint4*>(Bh32 + o) = make_uint4(h[0], h[1], h[2], h[3]);
-          *reinterpret_cast<uint4*>(Bh32 + B_PL / 2 + o) = make_uint4(l[0], l[1], l[2], l[3]);
+        for (int j = 0; j < NB; ++j) {
+          unsigned h0, l0, h1, l1;
+          split2(rb[sl][j].x, rb[sl][j].y, h0, l0);
+          split2(rb[sl][j].z, rb[sl][j].w, h1, l1);
+          const int o = tr_off<BN>(2 * (b_k0 + B_KSTEP * (j >> 1)) + (j & 1), b_mc >> 1) + 8 * (b_mc & 1);
+          *reinterpret_cast<uint2*>(Bhb + o) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(Bhb + 2 * B_PL + o) = make_uint2(l0, l1);
         }
       }
     }
@@ -453,6 +448,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
+  // transposed fragment reads ([k][mn] images of the mn-contiguous operands): lane = 32 h + 16 c + 4 q + p supplies the address of
+  // row q, columns 4 p .. 4 p + 3 of its 16-lane group's 4 x 16 block (column half c of the 32-wide fragment, k half h)
+  const int tr_h = lane >> 5, tr_c = (lane >> 4) & 1, tr_q = (lane >> 2) & 3, tr_p = lane & 3;
 
   auto compute_groups = [&](int buf, int g0, int g1) {
     if constexpr (PREC == 1) {
@@ -468,13 +466,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
           ahi[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
           alo[i] = *reinterpret_cast<const bf16x8*>(Ah + A_PL + ao);
         } else {
-          const unsigned* A32 = reinterpret_cast<const unsigned*>(Ah);
-          const int ao = (ks * 8 + 4 * lh) * PMA_LD + wm * WTM + 32 * i + l31;
-          const uint4 h4 = make_uint4(A32[ao], A32[ao + PMA_LD], A32[ao + 2 * PMA_LD], A32[ao + 3 * PMA_LD]);
-          const uint4 l4 = make_uint4(A32[A_PL / 2 + ao], A32[A_PL / 2 + ao + PMA_LD], A32[A_PL / 2 + ao + 2 * PMA_LD],
-                                      A32[A_PL / 2 + ao + 3 * PMA_LD]);
-          ahi[i] = __builtin_bit_cast(bf16x8, h4);
-          alo[i] = __builtin_bit_cast(bf16x8, l4);
+          // [k][m] image: two transposed 4-row reads per plane deliver the lane's 8 consecutive k of its row (lane & 31)
+          const char* Ab = reinterpret_cast<const char*>(Ah) + tr_off<BM>(ks * 16 + 8 * tr_h + tr_q, ((wm * WTM + 32 * i) >> 3) + 2 * tr_c + (tr_p >> 1)) + 8 * (tr_p & 1);
+          ahi[i] = tr_read8(Ab, 4 * BM * 2);
+          alo[i] = tr_read8(Ab + 2 * A_PL, 4 * BM * 2);
         }
       }
 #pragma unroll
@@ -484,13 +479,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
           bhi[j] = *reinterpret_cast<const bf16x8*>(Bh + bo);
           blo[j] = *reinterpret_cast<const bf16x8*>(Bh + B_PL + bo);
         } else {
-          const unsigned* B32 = reinterpret_cast<const unsigned*>(Bh);
-          const int bo = (ks * 8 + 4 * lh) * PMB_LD + wn * WTN + 32 * j + l31;
-          const uint4 h4 = make_uint4(B32[bo], B32[bo + PMB_LD], B32[bo + 2 * PMB_LD], B32[bo + 3 * PMB_LD]);
-          const uint4 l4 = make_uint4(B32[B_PL / 2 + bo], B32[B_PL / 2 + bo + PMB_LD], B32[B_PL / 2 + bo + 2 * PMB_LD],
-                                      B32[B_PL / 2 + bo + 3 * PMB_LD]);
-          bhi[j] = __builtin_bit_cast(bf16x8, h4);
-          blo[j] = __builtin_bit_cast(bf16x8, l4);
+          const char* Bb = reinterpret_cast<const char*>(Bh) + tr_off<BN>(ks * 16 + 8 * tr_h + tr_q, ((wn * WTN + 32 * j) >> 3) + 2 * tr_c + (tr_p >> 1)) + 8 * (tr_p & 1);
+          bhi[j] = tr_read8(Bb, 4 * BN * 2);
+          blo[j] = tr_read8(Bb + 2 * B_PL, 4 * BN * 2);
         }
       }
 #pragma unroll
