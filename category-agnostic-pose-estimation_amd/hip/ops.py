@@ -292,7 +292,7 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     d.rng_stream = rng_stream
     d.precision = GEMM_PRECISION
     if (packed is None and PackedWeights.enabled and GEMM_PRECISION >= 1 and a_mode == 0 and b_mode in (0, 1) and batch is None
-            and split_k == 1 and K in (64, 128, 256) and M > 64 and N >= 32):
+            and split_k == 1 and K in (64, 128, 256) and M > 64 and 32 <= N <= _PACK_MAX_N):
         packed = PackedWeights.lookup(B, N, K, d.ldb, b_mode)
     if packed is not None and GEMM_PRECISION >= 1:
         assert packed.dtype == torch.int16 and packed.is_cuda and packed.numel() * 2 >= lib.raw().cape_packed_weight_bytes(N, K)
@@ -359,6 +359,7 @@ def _group_ok(d):
             and (d.b_mode == 3 or d.ldb % 4 == 0) and max(d.lda, d.ldb, d.ldc) < (1 << 31))
 
 
+_PACK_MAX_N = int(os.environ.get("CAPE_PACK_MAX_N", "1000000"))      # tuning switch: widest product that reads packed weight planes
 _GROUP_BIG_MN = int(os.environ.get("CAPE_GROUP_BIG_MN", str(64 * 1024)))      # tuning switch
 
 
