@@ -37,10 +37,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bid) {
 
   // two LDS buffers per operand: tile t+1 is written into the other buffer in the middle of tile t's MFMAs
   // (one barrier per k-tile; a single wave per SIMD keeps the matrix pipe fed)
-  // PREC 1: per operand and buffer two bf16 planes (hi, lo) laid out [row][k] with an 80-byte row stride
-  // (32 k x 2 B + 16 B pad: conflict-free ds_read_b128 of 8 consecutive k per lane)
+  // PREC 1: per operand and buffer two bf16 planes (hi, lo).  k-contiguous operands: [row][k] with an 80-byte row stride
+  // (32 k x 2 B + 16 B pad: conflict-free ds_read_b128 of 8 consecutive k per lane); mn-contiguous operands: the swizzled
+  // [k][mn] image of gemm_common.h tr_off (32 rows of BM / BN bf16), read with ds_read_b64_tr_b16 -- it fits in the same plane
   constexpr int PL_LD = 40;                                    // bf16 elements per row ([row][k] image)
-  constexpr int PMA_LD = BM + 4, PMB_LD = BN + 4;              // 32-bit words per k-pair row ([k/2][mn] image)
   constexpr int A_PL = BM * PL_LD, B_PL = BN * PL_LD;          // elements per plane
   constexpr int A_WORDS = PREC ? A_PL : A_SZ;                  // 2 planes x A_PL bf16 = A_PL 32-bit words
   constexpr int B_WORDS = PREC ? B_PL : B_SZ;
