@@ -269,6 +269,16 @@ def gemm(A, B, C, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None, bia
     is a parameter (or a view of one) and the product is one the register-stationary kernel takes."""
     for t, n in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (scale, "scale"), (residual, "residual")):
         _chk(t, "gemm." + n, contiguous=False)
+    if (_AUTO_SPLIT_NN and a_mode == 0 and b_mode == 1 and split_k == 1 and K >= 512 and M > 64 and batch is None and conv is None
+            and bias is None and scale is None and residual is None and not relu and mask_src is None and dropout_p == 0.0
+            and colsum_out is None and (ldc is None or ldc == N) and C.is_contiguous() and ((M + 63) // 64) * ((N + 63) // 64) <= 64):
+        # plain data gradients with few output tiles over a deep contraction (the support path: 544 rows against K = 512 / 1024 =
+        # 36 tiles of 16-32 sequential k-tiles, 21-35 us of pure latency): k-split with atomic accumulation
+        sk = pick_split_k(M, N, K)
+        if sk >= 4 and _avail(C) >= M * N:
+            if not accumulate:
+                C.view(-1)[:M * N].zero_()
+            split_k, accumulate = sk, True
     d = lib.GemmDesc()
     d.M, d.N, d.K, d.a_mode, d.b_mode = M, N, K, a_mode, b_mode
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
@@ -359,6 +369,7 @@ def _group_ok(d):
             and (d.b_mode == 3 or d.ldb % 4 == 0) and max(d.lda, d.ldb, d.ldc) < (1 << 31))
 
 
+_AUTO_SPLIT_NN = os.environ.get("CAPE_AUTO_SPLIT_NN", "1") == "1" and os.environ.get("CAPE_DETERMINISTIC", "0") != "1"
 _PACK_MAX_N = int(os.environ.get("CAPE_PACK_MAX_N", "1000000"))      # tuning switch: widest product that reads packed weight planes
 _GROUP_BIG_MN = int(os.environ.get("CAPE_GROUP_BIG_MN", str(64 * 1024)))      # tuning switch
 
