@@ -646,7 +646,8 @@ def test_attention_matrix_core_form_dropout_consistent():
     close(dQ, dQf.cpu(), tol=5e-4, name="dQ"); close(dK, dKf.cpu(), tol=5e-4, name="dK"); close(dV, dVf.cpu(), tol=5e-4, name="dV")
 
 
-@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 72, 128, 2), (1, 64, 200, 0), (2, 224, 224, 1), (1, 33, 97, 1), (2, 200, 40, 0)])
+@pytest.mark.parametrize("N,Lq,Lk,mode", [(2, 200, 200, 1), (3, 72, 128, 2), (1, 64, 200, 0), (2, 224, 224, 1), (1, 33, 97, 1), (2, 200, 40, 0),
+                                          (3, 200, 17, 2), (4, 17, 17, 2), (2, 9, 9, 0), (2, 1, 37, 0)])      # few keys / few queries
 def test_flash_attention_fwd_bwd(N, Lq, Lk, mode):
     """csrc/flash_attn.hip (fused Q K^T -> mask -> softmax -> P V on the matrix cores, backward recomputed from the log-sum-exp)
     against the plain torch expression on the CPU: strided q | k | v views of one (N, L, 768) buffer as the decoder passes
