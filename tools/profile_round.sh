@@ -15,7 +15,8 @@ f=$(find $out/stats -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stat
 # keep the merge-back small: the per-dispatch traces are large
 find $out/stats $out/fetch $out/write -name "*.csv" -size +4M -delete
 # the bench line of the same tree on the same box (with the roofline leg; profiles/<tag>_gemm_traffic.json must already hold this
-# tree's traffic for `traffic_stale: false`, so the driver copies it first)
+# tree's traffic for `traffic_stale: false`, so the script copies it first -- on the GPU box only: after the call, copy
+# gpurun_out/<dir>/{gemm_traffic.json,kernel_stats.csv,bench_line.json} into profiles/ by hand and run tools/round_summary.py)
 if [ -n "$2" ]; then cp $out/gemm_traffic.json profiles/$2_gemm_traffic.json; fi
 python3 bench.py --steps 20 --warmup 3 > $out/bench_line.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
 head -12 $out/kernel_stats.csv | cut -c1-200
