@@ -232,7 +232,9 @@ class TransformerDecoder(nn.Module):
             reference_points, r_keep = HF.fanout(HF.refine(delta, r_ref), 2)   # no detach between layers (:1096-1102)
             cls = HF.linear(o_cls, self.class_embed[lid].weight, self.class_embed[lid].bias)
             hs.append(o_hs); refs.append(r_keep); clss.append(cls)
-        return torch.stack(hs), torch.stack(refs), torch.stack(clss)
+        # (the reference stacks the six hidden states, deformable_transformer_v2.py:1128; its only reader takes hs[-1]
+        # (roomformer_v2.py:343): the list serves that without a 39 MB copy and the zero-filled gradient of the unread layers)
+        return hs, torch.stack(refs), torch.stack(clss)
 
     @torch.no_grad()
     def decode_step(self, tok, delta, ref_step, geo, valid_ratios, step, caches):
